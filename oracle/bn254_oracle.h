@@ -1,0 +1,89 @@
+/*
+ * oracle/bn254_oracle.h — CPU restatement of the Spartan-BN254 prover hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (spartan-bn254_amd/,
+ * include/) may include, link or call this.  Allowed users: tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg, as the checker.
+ *
+ * Parity status: the reference (Rust) delegates the MSM arithmetic to
+ * ark-ec / ark-ff / ark-bn254 0.5 (Cargo.toml:9-11, not vendored, Cargo.lock
+ * ignored) and ships NO golden vectors for this path.  Byte-level MSM /
+ * commitment output is therefore "parity unpinned" by reference fixtures.  What
+ * IS pinned (tests/test_oracle_*.py): the reference's own unit-test relations
+ * (group.rs:313-321 2G+3G=5G; unipoly.rs:130-184 interpolation KATs;
+ * hyrax.rs:427-470; sumcheck.rs:818-861; scalar.rs:206-215), the published
+ * wire formats, and an independent pure-Python big-integer
+ * model of the mathematical definition (tests/pyref.py -> tests/golden/).
+ * Canonical affine coordinates of a group element are unique, so agreement with
+ * the mathematical definition is agreement with arkworks' result.
+ *
+ * All byte interfaces: scalars = 32 B little-endian canonical integers < r
+ * (scalar.rs:75-95); points = x||y, each 32 B little-endian canonical < p,
+ * the all-zero 64 B string meaning the point at infinity.
+ */
+#ifndef BN254_ORACLE_H
+#define BN254_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- field helpers on canonical LE bytes; which = 0 -> Fq, 1 -> Fr ---- */
+int  orc_fe_is_canonical(int which, const uint8_t a[32]);
+void orc_fe_add(int which, const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void orc_fe_sub(int which, const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void orc_fe_mul(int which, const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void orc_fe_inv(int which, const uint8_t a[32], uint8_t out[32]);
+/* 64 bytes LE reduced mod r (transcript.rs:56-67 from_le_bytes_mod_order) */
+void orc_fr_from_wide(const uint8_t in[64], uint8_t out[32]);
+/* sum_i k_i * s_i mod r  (the dlog oracle of SURVEY §0.7) */
+void orc_fr_dot(const uint8_t* k, const uint8_t* s, size_t n, uint8_t out[32]);
+
+/* ---- G1 on canonical affine bytes ---- */
+int  orc_g1_on_curve(const uint8_t p[64]);
+void orc_g1_add(const uint8_t p[64], const uint8_t q[64], uint8_t out[64]);
+void orc_g1_neg(const uint8_t p[64], uint8_t out[64]);
+void orc_g1_mul(const uint8_t p[64], const uint8_t k[32], uint8_t out[64]);
+/* arkworks serialize_compressed (group.rs:135-140): x LE, bit7 of byte31 = y>p-y, bit6 = infinity */
+void orc_g1_compress(const uint8_t p[64], uint8_t out[32]);
+int  orc_g1_decompress(const uint8_t in[32], uint8_t out[64]);
+/* n fixed-base multiples s_i*G of the generator (1,2); used for fixtures with known dlogs */
+void orc_g1_mul_gen_batch(const uint8_t* s, size_t n, uint8_t* out_xy, int threads);
+
+/* ---- MSM (group.rs:143-158, 171-175) ---- */
+/* definition: double-and-add per term */
+void orc_msm_naive(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out[64]);
+/* arkworks-0.5-style signed-digit Pippenger, `threads` over windows like ark-ec/parallel */
+void orc_msm_pippenger(const uint8_t* scalars, const uint8_t* bases, size_t n, uint8_t out[64], int threads);
+int  orc_msm_window_bits(size_t n);
+
+/* ---- Pedersen generators + commit (commitments.rs:31-62, 118-154; group.rs:110-131) ---- */
+/* writes (n+1) points: G[0..n) then h; dlogs (optional, may be NULL) gets the (n+1) scalars s_i with P_i = s_i*G */
+void orc_gens_new(size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, uint8_t* out_dlogs, int threads);
+/* commit = MSM(scalars || blind, G || h)  (commitments.rs:144-154) */
+void orc_commit(const uint8_t* scalars, size_t n, const uint8_t blind[32], const uint8_t* G_xy, const uint8_t h_xy[64], uint8_t out[64]);
+/* Hyrax row commit (hyrax.rs:253-267): C[i] = commit(Z[i*R..(i+1)*R], blinds[i]); blinds NULL = zeros; threads over rows like rayon */
+void orc_commit_rows(const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R, const uint8_t* G_xy, const uint8_t h_xy[64], uint8_t* out_xy, int threads);
+/* hyrax.rs:371-373 */
+void orc_factored_lens(size_t ell, size_t* left, size_t* right);
+
+/* ---- multilinear / sumcheck (hyrax.rs:195-203, 355-369; sumcheck.rs) ---- */
+void orc_eq_evals(const uint8_t* r, size_t ell, uint8_t* out /* 2^ell x 32 */);
+void orc_bind_top(uint8_t* Z, size_t len, const uint8_t r[32]);  /* in place; first len/2 entries valid after */
+void orc_sc_eval_cubic(const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, uint8_t out[96]);        /* e0,e2,e3 of A*B*C      (sumcheck.rs:111-135) */
+void orc_sc_eval_r1cs(const uint8_t* T, const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, uint8_t out[96]); /* T*(A*B-C) (sumcheck.rs:502-530, r1csproof.rs:288-292) */
+void orc_sc_eval_quad(const uint8_t* Z, const uint8_t* ABC, size_t len, uint8_t out[64]);                        /* e0,e2 of Z*ABC         (sumcheck.rs:691-699) */
+/* unipoly.rs:28-59: evals at 0,1,2[,3] -> coefficients low..high; n = 3 or 4 */
+void orc_unipoly_from_evals(const uint8_t* evals, size_t n, uint8_t* coeffs);
+void orc_unipoly_eval(const uint8_t* coeffs, size_t n, const uint8_t r[32], uint8_t out[32]);
+void orc_dotproduct(const uint8_t* a, const uint8_t* b, size_t n, uint8_t out[32]);
+
+/* ---- Keccak (sha3 crate call sites: commitments.rs:33-44, group.rs:113-128) ---- */
+void orc_sha3_256(const uint8_t* in, size_t len, uint8_t out[32]);
+void orc_shake256(const uint8_t* in, size_t len, uint8_t* out, size_t outlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
