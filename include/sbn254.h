@@ -1,0 +1,129 @@
+/*
+ * sbn254.h — C ABI of libsbn254_hip.so: the MI355X (gfx950) implementation of Spartan-BN254's prover
+ * hot path.  These are the entry points a Rust `extern "C"` block binds (INTEGRATION.md shows the shim);
+ * every function cites the reference interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - return 0 on success, a negative SBN_E* code otherwise; sbn_last_error() has the text.
+ *     The reference's prover functions are infallible (assert!/panic on misuse, errors.rs:19-31 is
+ *     verifier-only), so the shim turns a non-zero code into panic!.
+ *   - scalars: 32 B little-endian.  Default = canonical integer < r (Scalar::to_bytes, scalar.rs:75-84);
+ *     with SBN_SCALARS_MONT the 4 x u64 Montgomery limbs ark-ff keeps in memory (R = 2^256) are taken as-is.
+ *   - points: 64 B = x || y, each 32 B little-endian canonical integer < p; all-zero = point at infinity.
+ *     With SBN_POINTS_MONT the coordinates are ark-ff Montgomery limbs instead (G1Affine's in-memory x, y).
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc'ed by the caller or by sbn_dev_alloc); the others take
+ *     host pointers and stage through HBM themselves.
+ *   - a context owns one HIP stream and a workspace; calls on one context are serialised by a mutex
+ *     (hyrax.rs:259-261 may enter B1 from many rayon workers at once); use one context per thread for overlap.
+ *   - there is NO CPU fallback: without a gfx950 device sbn_ctx_create fails.
+ */
+#ifndef SBN254_H
+#define SBN254_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBN_OK 0
+#define SBN_EINVAL (-1)   /* bad argument (NULL, size mismatch, non-canonical input when checked) */
+#define SBN_EHIP (-2)     /* HIP runtime error */
+#define SBN_ENODEV (-3)   /* no usable gfx950 device */
+#define SBN_ENOMEM (-4)
+
+#define SBN_SCALARS_MONT 1u
+#define SBN_POINTS_MONT 2u
+
+typedef struct sbn_ctx sbn_ctx;
+typedef struct sbn_bases sbn_bases;   /* device-resident generator table: MultiCommitGens.{G_affine,h_affine} (commitments.rs:17-27) */
+typedef struct sbn_table sbn_table;   /* device-resident Fr table: DensePolynomial.Z (hyrax.rs:155-160) */
+
+/* ---- context ---- */
+int sbn_ctx_create(int device, sbn_ctx** out);
+void sbn_ctx_destroy(sbn_ctx* ctx);
+const char* sbn_last_error(const sbn_ctx* ctx);
+/* run on the caller's HIP stream (hipStream_t as void*); NULL restores the context's own stream */
+int sbn_ctx_set_stream(sbn_ctx* ctx, void* hip_stream);
+int sbn_ctx_sync(sbn_ctx* ctx);
+const char* sbn_version(void);
+
+/* ---- raw device memory for callers without their own allocator (the Rust shim) ---- */
+int sbn_dev_alloc(sbn_ctx* ctx, size_t bytes, void** out_dev);
+int sbn_dev_free(sbn_ctx* ctx, void* dev);
+int sbn_dev_upload(sbn_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int sbn_dev_download(sbn_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- B1: single MSM — GroupElement::msm_affine(scalars, points) (group.rs:171-175) and
+ *      vartime_multiscalar_mul (group.rs:143-158).  out_is_inf may be NULL.
+ *      n == 0 returns the identity, as arkworks' msm of empty slices does. ---- */
+int sbn_msm(sbn_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint32_t flags,
+            uint8_t out_xy[64], int* out_is_inf);
+
+/* ---- generator tables — MultiCommitGens (commitments.rs:17-27).  G: n points, h: 1 point or NULL.
+ *      Stored on the device in Montgomery form; duplicates are detected so that commit() can merge the
+ *      scalars of equal bases (the reference's derivation makes ~66 % of them equal to G, group.rs:110-131). ---- */
+int sbn_bases_upload(sbn_ctx* ctx, const uint8_t* G_xy, size_t n, const uint8_t* h_xy, uint32_t flags, sbn_bases** out);
+void sbn_bases_free(sbn_ctx* ctx, sbn_bases* b);
+size_t sbn_bases_len(const sbn_bases* b);          /* n (without h) */
+/* MultiCommitGens::new(n, label) (commitments.rs:31-62): SHAKE256 stream -> from_uniform_bytes (group.rs:110-131);
+ * builds G[0..n) and h on the device and, if out_xy != NULL, also returns the n+1 canonical points. */
+int sbn_gens_new(sbn_ctx* ctx, size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, sbn_bases** out);
+
+/* MSM of n scalars against the first n points of a resident table (no h): msm_affine with cached G_affine */
+int sbn_msm_bases(sbn_ctx* ctx, const sbn_bases* b, const uint8_t* scalars, size_t n, uint32_t flags,
+                  uint8_t out_xy[64], int* out_is_inf);
+int sbn_msm_bases_dev(sbn_ctx* ctx, const sbn_bases* b, const void* scalars_dev, size_t n, uint32_t flags,
+                      uint8_t out_xy[64], int* out_is_inf);
+
+/* ---- B2: Pedersen / Hyrax commitments ----
+ * <[Scalar] as Commitments>::commit(blind, gens_n) = MSM(scalars || blind, G || h) (commitments.rs:144-154):
+ *   sbn_commit_rows with L = 1.
+ * DensePolynomial::commit -> commit_inner (hyrax.rs:253-267, 283-308): C[i] = commit(Z[i*R..(i+1)*R], blinds[i]),
+ *   Z row-major L x R, R == sbn_bases_len(b), blinds NULL = all zero (random_tape == None, hyrax.rs:301-305).
+ * out_xy: L x 64 B canonical affine; out_inf: L flags or NULL. */
+int sbn_commit_rows(sbn_ctx* ctx, const sbn_bases* b, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R,
+                    uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
+int sbn_commit_rows_dev(sbn_ctx* ctx, const sbn_bases* b, const void* Z_dev, const void* blinds_dev, size_t L, size_t R,
+                        uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
+/* arkworks serialize_compressed of n affine points (group.rs:135-140; what transcript.rs:102-108 absorbs) */
+int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32);
+/* EqPolynomial::compute_factored_lens (hyrax.rs:371-373) */
+void sbn_factored_lens(size_t ell, size_t* left, size_t* right);
+
+/* ---- B3: sumcheck rounds on device-resident tables ----
+ * A table is a DensePolynomial's Z vector (len a power of two).  Each eval returns the per-round values the
+ * host needs for UniPoly::from_evals (unipoly.rs:28-59) as canonical 32 B scalars. */
+int sbn_table_upload(sbn_ctx* ctx, const uint8_t* Z, size_t len, uint32_t flags, sbn_table** out);
+int sbn_table_from_dev(sbn_ctx* ctx, const void* Z_dev, size_t len, uint32_t flags, sbn_table** out);
+void sbn_table_free(sbn_ctx* ctx, sbn_table* t);
+size_t sbn_table_len(const sbn_table* t);                                   /* current len (halves per bind) */
+int sbn_table_download(sbn_ctx* ctx, const sbn_table* t, uint8_t* out /* len x 32 canonical */);
+int sbn_table_read0(sbn_ctx* ctx, const sbn_table* t, uint8_t out[32]);     /* poly[0] after the last round (sumcheck.rs:157) */
+/* DensePolynomial::bound_poly_var_top(r) (hyrax.rs:195-203) */
+int sbn_bind_top(sbn_ctx* ctx, sbn_table* t, const uint8_t r[32]);
+int sbn_bind_top_many(sbn_ctx* ctx, sbn_table* const* ts, size_t count, const uint8_t r[32]);
+/* prove_cubic inner loop, comb = A*B*C (sumcheck.rs:111-135; product_tree.rs:178-181): out = e0,e2,e3 */
+int sbn_sc_eval_cubic(sbn_ctx* ctx, const sbn_table* A, const sbn_table* B, const sbn_table* C, uint8_t out[96]);
+/* prove_cubic_batched inner loops (sumcheck.rs:201-267): instance i uses (A[i], B[i], C[i]); pass the shared
+ * poly_C_par for the "par" instances.  out = count x (e0,e2,e3) */
+int sbn_sc_eval_cubic_batched(sbn_ctx* ctx, const sbn_table* const* A, const sbn_table* const* B,
+                              const sbn_table* const* C, size_t count, uint8_t* out /* count x 96 */);
+/* prove_cubic_with_additive_term inner loop, comb = tau*(Az*Bz - Cz) (sumcheck.rs:502-530; r1csproof.rs:288-292) */
+int sbn_sc_eval_r1cs(sbn_ctx* ctx, const sbn_table* tau, const sbn_table* Az, const sbn_table* Bz, const sbn_table* Cz,
+                     uint8_t out[96]);
+/* prove_quad inner loop, comb = z*ABC (sumcheck.rs:691-699; r1csproof.rs:389-390): out = e0,e2 */
+int sbn_sc_eval_quad(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* ABC, uint8_t out[64]);
+/* EqPolynomial::evals (hyrax.rs:355-369) built on the device */
+int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
+
+/* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline line ---- */
+int sbn_prof_enable(sbn_ctx* ctx, int on);
+int sbn_prof_reset(sbn_ctx* ctx);
+/* number of distinct kernel names seen; i-th name, summed ms and launch count */
+int sbn_prof_count(sbn_ctx* ctx);
+int sbn_prof_get(sbn_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,250 @@
+"""ctypes binding of include/sbn254.h.  Device pointers are plain ints (torch `tensor.data_ptr()`)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SBN_SCALARS_MONT = 1
+SBN_POINTS_MONT = 2
+
+EXPORTED_SYMBOLS = [
+    "sbn_ctx_create", "sbn_ctx_destroy", "sbn_last_error", "sbn_ctx_set_stream", "sbn_ctx_sync", "sbn_version",
+    "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
+    "sbn_msm", "sbn_bases_upload", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new",
+    "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_factored_lens",
+    "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
+    "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
+    "sbn_eq_evals", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+]
+
+
+class SbnError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsbn254_hip.so")
+
+
+def build_library():
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+    return lib_path()
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise SbnError(f"{p} is missing: run `make -C {_HERE}` (or __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(p)
+        L.sbn_last_error.restype = C.c_char_p
+        L.sbn_version.restype = C.c_char_p
+        missing = [s for s in EXPORTED_SYMBOLS if not hasattr(L, s)]
+        if missing:
+            raise SbnError(f"{p} does not export {missing}; rebuild it")
+        L.sbn_bases_len.restype = C.c_size_t
+        L.sbn_table_len.restype = C.c_size_t
+        L.sbn_factored_lens.restype = None
+        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free"):
+            getattr(L, name).restype = None
+        _LIB = L
+    return _LIB
+
+
+def _ptr(x):
+    """host bytes-like -> char pointer; None -> NULL"""
+    if x is None:
+        return None
+    if isinstance(x, (bytes, bytearray)):
+        return (C.c_uint8 * len(x)).from_buffer_copy(x) if isinstance(x, bytes) else (C.c_uint8 * len(x)).from_buffer(x)
+    if hasattr(x, "ctypes"):  # numpy array
+        return x.ctypes.data_as(C.POINTER(C.c_uint8))
+    raise TypeError(type(x))
+
+
+def g1_compress(xy):
+    n = len(xy) // 64
+    out = (C.c_uint8 * (32 * n))()
+    rc = lib().sbn_g1_compress(_ptr(xy), C.c_size_t(n), out)
+    if rc:
+        raise SbnError(f"sbn_g1_compress rc={rc}")
+    return bytes(out)
+
+
+def factored_lens(ell):
+    a, b = C.c_size_t(), C.c_size_t()
+    lib().sbn_factored_lens(C.c_size_t(ell), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+class Bases:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return lib().sbn_bases_len(self.h)
+
+    def free(self):
+        if self.h:
+            lib().sbn_bases_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Table:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return lib().sbn_table_len(self.h)
+
+    def free(self):
+        if self.h:
+            lib().sbn_table_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Context:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().sbn_ctx_create(device, C.byref(self.h))
+        if rc:
+            raise SbnError(f"sbn_ctx_create failed rc={rc} (no gfx950 device? there is no CPU fallback)")
+
+    def close(self):
+        if self.h:
+            lib().sbn_ctx_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc, what):
+        if rc:
+            raise SbnError(f"{what}: rc={rc}: {lib().sbn_last_error(self.h).decode()}")
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().sbn_ctx_set_stream(self.h, C.c_void_p(stream_ptr)), "set_stream")
+
+    def sync(self):
+        self._chk(lib().sbn_ctx_sync(self.h), "sync")
+
+    # ---- B1
+    def msm(self, scalars, points, flags=0):
+        n = len(scalars) // 32
+        assert len(points) == 64 * n
+        out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_msm(self.h, _ptr(scalars), _ptr(points), C.c_size_t(n), C.c_uint32(flags), out, C.byref(inf)), "sbn_msm")
+        return bytes(out), bool(inf.value)
+
+    def bases_upload(self, G_xy, h_xy=None, flags=0):
+        n = len(G_xy) // 64
+        hb = C.c_void_p()
+        self._chk(lib().sbn_bases_upload(self.h, _ptr(G_xy), C.c_size_t(n), _ptr(h_xy), C.c_uint32(flags), C.byref(hb)), "sbn_bases_upload")
+        return Bases(self, hb)
+
+    def gens_new(self, n, label, want_points=True):
+        hb = C.c_void_p()
+        out = (C.c_uint8 * (64 * (n + 1)))() if want_points else None
+        self._chk(lib().sbn_gens_new(self.h, C.c_size_t(n), _ptr(label), C.c_size_t(len(label)), out, C.byref(hb)), "sbn_gens_new")
+        return Bases(self, hb), (bytes(out) if want_points else None)
+
+    def msm_bases(self, bases, scalars, flags=0):
+        n = len(scalars) // 32
+        out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_msm_bases(self.h, bases.h, _ptr(scalars), C.c_size_t(n), C.c_uint32(flags), out, C.byref(inf)), "sbn_msm_bases")
+        return bytes(out), bool(inf.value)
+
+    def msm_bases_dev(self, bases, scalars_dev_ptr, n, flags=0):
+        out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_msm_bases_dev(self.h, bases.h, C.c_void_p(scalars_dev_ptr), C.c_size_t(n), C.c_uint32(flags), out, C.byref(inf)), "sbn_msm_bases_dev")
+        return bytes(out), bool(inf.value)
+
+    # ---- B2
+    def commit_rows(self, bases, Z, blinds, L, R, flags=0):
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_commit_rows(self.h, bases.h, _ptr(Z), _ptr(blinds), C.c_size_t(L), C.c_size_t(R), C.c_uint32(flags), out, inf), "sbn_commit_rows")
+        return bytes(out), bytes(inf)
+
+    def commit_rows_dev(self, bases, Z_dev_ptr, blinds_dev_ptr, L, R, flags=0):
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_commit_rows_dev(self.h, bases.h, C.c_void_p(Z_dev_ptr), C.c_void_p(blinds_dev_ptr or 0), C.c_size_t(L), C.c_size_t(R), C.c_uint32(flags), out, inf), "sbn_commit_rows_dev")
+        return bytes(out), bytes(inf)
+
+    # ---- raw device memory
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p(); self._chk(lib().sbn_dev_alloc(self.h, C.c_size_t(nbytes), C.byref(p)), "sbn_dev_alloc"); return p.value
+
+    def dev_free(self, p):
+        self._chk(lib().sbn_dev_free(self.h, C.c_void_p(p)), "sbn_dev_free")
+
+    def dev_upload(self, dst, data):
+        self._chk(lib().sbn_dev_upload(self.h, C.c_void_p(dst), _ptr(data), C.c_size_t(len(data) if not hasattr(data, "nbytes") else data.nbytes)), "sbn_dev_upload")
+
+    def dev_download(self, src, nbytes):
+        out = (C.c_uint8 * nbytes)(); self._chk(lib().sbn_dev_download(self.h, out, C.c_void_p(src), C.c_size_t(nbytes)), "sbn_dev_download"); return bytes(out)
+
+    # ---- B3
+    def table_upload(self, Z, flags=0):
+        n = len(Z) // 32; ht = C.c_void_p()
+        self._chk(lib().sbn_table_upload(self.h, _ptr(Z), C.c_size_t(n), C.c_uint32(flags), C.byref(ht)), "sbn_table_upload")
+        return Table(self, ht)
+
+    def table_from_dev(self, dev_ptr, n, flags=0):
+        ht = C.c_void_p()
+        self._chk(lib().sbn_table_from_dev(self.h, C.c_void_p(dev_ptr), C.c_size_t(n), C.c_uint32(flags), C.byref(ht)), "sbn_table_from_dev")
+        return Table(self, ht)
+
+    def table_download(self, t):
+        n = len(t); out = (C.c_uint8 * (32 * n))()
+        self._chk(lib().sbn_table_download(self.h, t.h, out), "sbn_table_download"); return bytes(out)
+
+    def table_read0(self, t):
+        out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_read0(self.h, t.h, out), "sbn_table_read0"); return bytes(out)
+
+    def bind_top(self, t, r):
+        self._chk(lib().sbn_bind_top(self.h, t.h, _ptr(r)), "sbn_bind_top")
+
+    def bind_top_many(self, ts, r):
+        arr = (C.c_void_p * len(ts))(*[t.h for t in ts])
+        self._chk(lib().sbn_bind_top_many(self.h, arr, C.c_size_t(len(ts)), _ptr(r)), "sbn_bind_top_many")
+
+    def sc_eval_cubic(self, A, B, Cc):
+        out = (C.c_uint8 * 96)(); self._chk(lib().sbn_sc_eval_cubic(self.h, A.h, B.h, Cc.h, out), "sbn_sc_eval_cubic"); return bytes(out)
+
+    def sc_eval_cubic_batched(self, As, Bs, Cs):
+        k = len(As); mk = lambda ts: (C.c_void_p * k)(*[t.h for t in ts])
+        out = (C.c_uint8 * (96 * k))()
+        self._chk(lib().sbn_sc_eval_cubic_batched(self.h, mk(As), mk(Bs), mk(Cs), C.c_size_t(k), out), "sbn_sc_eval_cubic_batched"); return bytes(out)
+
+    def sc_eval_r1cs(self, T, A, B, Cc):
+        out = (C.c_uint8 * 96)(); self._chk(lib().sbn_sc_eval_r1cs(self.h, T.h, A.h, B.h, Cc.h, out), "sbn_sc_eval_r1cs"); return bytes(out)
+
+    def sc_eval_quad(self, Z, ABC):
+        out = (C.c_uint8 * 64)(); self._chk(lib().sbn_sc_eval_quad(self.h, Z.h, ABC.h, out), "sbn_sc_eval_quad"); return bytes(out)
+
+    def eq_evals(self, r):
+        ell = len(r) // 32; ht = C.c_void_p()
+        self._chk(lib().sbn_eq_evals(self.h, _ptr(r), C.c_size_t(ell), C.byref(ht)), "sbn_eq_evals"); return Table(self, ht)
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self._chk(lib().sbn_prof_enable(self.h, int(on)), "prof_enable")
+
+    def prof_reset(self):
+        self._chk(lib().sbn_prof_reset(self.h), "prof_reset")
+
+    def prof_get(self):
+        res = {}
+        for i in range(lib().sbn_prof_count(self.h)):
+            name = C.c_char_p(); ms = C.c_double(); cnt = C.c_uint64()
+            lib().sbn_prof_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt))
+            res[name.value.decode()] = (ms.value, cnt.value)
+        return res

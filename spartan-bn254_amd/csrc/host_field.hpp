@@ -1,0 +1,113 @@
+// host_field.hpp — host-side (CPU) BN254 Fq / G1 helpers used by the product's launch code.
+//
+// What runs here is the part of Pippenger that is a strictly sequential chain of ~254 doublings
+// (combining the per-window sums: sum_w 2^(c*w) * S_w).  A lone GPU lane needs ~1 us per modular
+// product (fp.cuh), i.e. ~2 ms for that chain; one host core does it in ~0.1 ms.  This is product
+// code (4 x 64-bit limbs, Jacobian) and shares nothing with oracle/ — the oracle stays a checker.
+// Reference semantics: group.rs:171-175 (the sum is returned as a group element; we hand back its
+// canonical affine coordinates).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace sbn_host {
+
+typedef unsigned __int128 u128;
+struct Fq { uint64_t v[4]; };
+
+static const uint64_t QP[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static const uint64_t QONE[4] = {0xd35d438dc58f0d9dull, 0x0a78eb28f5c70b3dull, 0x666ea36f7879462cull, 0x0e0a77c19a07df2full};
+static const uint64_t QR2[4] = {0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full};
+static const uint64_t QNINV = 0x87d20782e4866389ull;
+
+static inline bool geq_p(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--) { if (a[i] > QP[i]) return true; if (a[i] < QP[i]) return false; }
+  return true;
+}
+static inline void sub_p(uint64_t a[4]) {
+  uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - QP[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 127); }
+}
+static inline bool is_zero(const Fq& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+static inline bool eq(const Fq& a, const Fq& b) { return memcmp(a.v, b.v, 32) == 0; }
+static inline Fq add(const Fq& a, const Fq& b) {
+  Fq r; uint64_t c = 0;
+  for (int i = 0; i < 4; i++) { u128 s = (u128)a.v[i] + b.v[i] + c; r.v[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+  if (c || geq_p(r.v)) sub_p(r.v);
+  return r;
+}
+static inline Fq sub(const Fq& a, const Fq& b) {
+  Fq r; uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.v[i] - b.v[i] - br; r.v[i] = (uint64_t)d; br = (uint64_t)(d >> 127); }
+  if (br) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)r.v[i] + QP[i] + c; r.v[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+  return r;
+}
+// interleaved (CIOS) Montgomery product
+static inline Fq mul(const Fq& a, const Fq& b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < 4; j++) { u128 s = (u128)a.v[j] * b.v[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    u128 s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+    uint64_t m = t[0] * QNINV;
+    s = (u128)m * QP[0] + t[0]; c = (uint64_t)(s >> 64);
+    for (int j = 1; j < 4; j++) { s = (u128)m * QP[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+  }
+  Fq r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq_p(r.v)) sub_p(r.v);
+  return r;
+}
+static inline Fq sqr(const Fq& a) { return mul(a, a); }
+static inline Fq dbl(const Fq& a) { return add(a, a); }
+static inline Fq one() { Fq r; memcpy(r.v, QONE, 32); return r; }
+static inline Fq zero() { Fq r = {{0, 0, 0, 0}}; return r; }
+static inline Fq inv(const Fq& a) {
+  uint64_t e[4] = {QP[0] - 2, QP[1], QP[2], QP[3]};
+  Fq acc = one();
+  for (int i = 255; i >= 0; i--) { acc = sqr(acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, a); }
+  return acc;
+}
+static inline Fq from_mont(const Fq& a) { Fq o = {{1, 0, 0, 0}}; return mul(a, o); }
+static inline Fq to_mont(const Fq& a) { Fq r2; memcpy(r2.v, QR2, 32); return mul(a, r2); }
+
+// XYZZ point, same layout as the device's (4 x 32 B, Montgomery limbs little-endian)
+struct Pt { Fq X, Y, ZZ, ZZZ; };
+static inline bool is_inf(const Pt& p) { return is_zero(p.ZZ); }
+static inline Pt inf() { Pt p; p.X = zero(); p.Y = zero(); p.ZZ = zero(); p.ZZZ = zero(); return p; }
+static inline Pt pdbl(const Pt& p) {
+  if (is_inf(p)) return p;
+  Fq U = dbl(p.Y), V = sqr(U), W = mul(U, V), S = mul(p.X, V), xx = sqr(p.X), M3 = add(dbl(xx), xx);
+  Pt r; r.X = sub(sub(sqr(M3), S), S); r.Y = sub(mul(M3, sub(S, r.X)), mul(W, p.Y)); r.ZZ = mul(V, p.ZZ); r.ZZZ = mul(W, p.ZZZ);
+  return r;
+}
+static inline Pt padd(const Pt& a, const Pt& b) {
+  if (is_inf(a)) return b;
+  if (is_inf(b)) return a;
+  Fq U1 = mul(a.X, b.ZZ), U2 = mul(b.X, a.ZZ), S1 = mul(a.Y, b.ZZZ), S2 = mul(b.Y, a.ZZZ);
+  Fq P = sub(U2, U1), R = sub(S2, S1);
+  if (is_zero(P)) return is_zero(R) ? pdbl(a) : inf();
+  Fq PP = sqr(P), PPP = mul(P, PP), Q = mul(U1, PP);
+  Pt r; r.X = sub(sub(sub(sqr(R), PPP), Q), Q); r.Y = sub(mul(R, sub(Q, r.X)), mul(S1, PPP));
+  r.ZZ = mul(mul(a.ZZ, b.ZZ), PP); r.ZZZ = mul(mul(a.ZZZ, b.ZZZ), PPP);
+  return r;
+}
+// canonical little-endian x||y (64 B), all-zero for infinity
+static inline void to_affine_bytes(const Pt& p, uint8_t out[64], int* is_inf_out) {
+  if (is_inf(p)) { memset(out, 0, 64); if (is_inf_out) *is_inf_out = 1; return; }
+  Fq I = inv(mul(p.ZZ, p.ZZZ));
+  Fq x = from_mont(mul(p.X, mul(I, p.ZZZ))), y = from_mont(mul(p.Y, mul(I, p.ZZ)));
+  memcpy(out, x.v, 32); memcpy(out + 32, y.v, 32);   // little-endian host
+  if (is_inf_out) *is_inf_out = 0;
+}
+// sum_w 2^(c*w) * S[w], w = 0..W-1 (Horner from the top window)
+static inline Pt combine_windows(const Pt* S, int W, int c) {
+  Pt acc = inf();
+  for (int w = W - 1; w >= 0; w--) {
+    for (int d = 0; d < c; d++) acc = pdbl(acc);
+    acc = padd(acc, S[w]);
+  }
+  return acc;
+}
+
+}  // namespace sbn_host

@@ -1,0 +1,584 @@
+// sbn254.hip — context, launch code and the C ABI (include/sbn254.h) of libsbn254_hip.so.
+//
+// Host-side mirror of the reference's operator boundary for the hot path:
+//   GroupElement::msm_affine            src/group.rs:171-175        -> sbn_msm / sbn_msm_bases*
+//   MultiCommitGens                     src/commitments.rs:17-114   -> sbn_bases_upload / sbn_gens_new
+//   Commitments::commit, commit_inner   src/commitments.rs:144-154, src/hyrax.rs:253-308 -> sbn_commit_rows*
+//   sumcheck prover loops / bind        src/sumcheck.rs, src/hyrax.rs:195-203            -> sbn_sc_* / sbn_bind_top
+// There is no CPU fallback in this file: every entry point needs the gfx950 device.
+#include "../../include/sbn254.h"
+#include "host_field.hpp"
+#include "msm_kernels.cuh"
+#include "sumcheck_kernels.cuh"
+#include "host_keccak.hpp"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace sbn;
+
+// ------------------------------------------------------------------------------------------------
+struct ProfEntry { std::string name; double ms = 0; uint64_t launches = 0; };
+struct PendingEvt { int idx; hipEvent_t e0, e1; };
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+};
+
+struct sbn_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  // workspace (grown on demand, never shrunk; no allocation in steady state)
+  DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp;
+  void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<PendingEvt> prof_pending;
+  std::vector<hipEvent_t> evt_pool;
+};
+
+struct sbn_bases {
+  size_t n = 0;           // number of G points
+  bool has_h = false;
+  void* d_pts = nullptr;  // (n + has_h) x 64 B, Montgomery affine
+};
+
+struct sbn_table {
+  void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
+};
+
+static int fail(sbn_ctx* c, int code, const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail((c), SBN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+static int ensure(sbn_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return SBN_OK;
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + (bytes >> 3);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return fail(c, SBN_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+  b.cap = want;
+  return SBN_OK;
+}
+static int ensure_pin(sbn_ctx* c, size_t bytes) {
+  if (bytes <= c->pin_cap) return SBN_OK;
+  if (c->pin) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+  HIPCHK(c, hipHostMalloc(&c->pin, bytes, hipHostMallocDefault));
+  c->pin_cap = bytes;
+  return SBN_OK;
+}
+
+// ---- profiling: HIP events around every launch on the stream the kernel runs on ----
+static int prof_index(sbn_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == name) return (int)i;
+  ProfEntry e; e.name = name; c->prof_entries.push_back(e); return (int)c->prof_entries.size() - 1;
+}
+static hipEvent_t evt_get(sbn_ctx* c) {
+  if (!c->evt_pool.empty()) { hipEvent_t e = c->evt_pool.back(); c->evt_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+static void prof_drain(sbn_ctx* c) {
+  for (auto& p : c->prof_pending) {
+    hipEventSynchronize(p.e1);
+    float ms = 0; hipEventElapsedTime(&ms, p.e0, p.e1);
+    c->prof_entries[p.idx].ms += ms; c->prof_entries[p.idx].launches += 1;
+    c->evt_pool.push_back(p.e0); c->evt_pool.push_back(p.e1);
+  }
+  c->prof_pending.clear();
+}
+struct ProfScope {
+  sbn_ctx* c; PendingEvt pe; bool on;
+  ProfScope(sbn_ctx* c_, const char* name) : c(c_), on(c_->prof) {
+    if (on) { pe.idx = prof_index(c, name); pe.e0 = evt_get(c); pe.e1 = evt_get(c); hipEventRecord(pe.e0, c->stream); }
+  }
+  ~ProfScope() { if (on) { hipEventRecord(pe.e1, c->stream); c->prof_pending.push_back(pe); } }
+};
+#define LAUNCH(c, name, kern, grid, block, ...) \
+  do { ProfScope _ps((c), name); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); } while (0)
+#define LAUNCHCHK(c) HIPCHK(c, hipGetLastError())
+
+// ------------------------------------------------------------------------------------------------
+static int ilog2_ceil(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// Window size for a single MSM of n terms.  Cost model: n*W mixed adds (10 products) + 2*W*2^(c-1) full adds
+// (14 products); tuned on MI355X.  SBN_MSM_C overrides for experiments.
+static MsmShape choose_shape(size_t n) {
+  int c;
+  const char* env = getenv("SBN_MSM_C");
+  if (env && atoi(env) >= 7 && atoi(env) <= 22) c = atoi(env);
+  else {
+    int lg = ilog2_ceil(n < 2 ? 2 : n);
+    c = lg - 4;
+    if (c < 7) c = 7;
+    if (c > 20) c = 20;
+  }
+  MsmShape s; s.c = c; s.nb = 1 << (c - 1);
+  int W = (254 + c - 1) / c;
+  int tb = 254 - (W - 1) * c;          // bits in the top window
+  if (tb > c - 1) W += 1;              // top digit + carry must stay <= 2^(c-1)
+  s.W = W;
+  return s;
+}
+
+// MSM over device-resident canonical scalars and Montgomery affine bases; result -> XYZZ on host, then affine bytes
+static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_bases, size_t n, uint8_t out_xy[64], int* out_is_inf) {
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
+  const MsmShape s = choose_shape(n);
+  const size_t NB = (size_t)s.W * s.nb;
+  int rc;
+  if ((rc = ensure(c, c->hist, NB * 4))) return rc;
+  if ((rc = ensure(c, c->offs, NB * 4))) return rc;
+  if ((rc = ensure(c, c->cursor, NB * 4))) return rc;
+  if ((rc = ensure(c, c->sorted, (size_t)s.W * n * 4))) return rc;
+  if ((rc = ensure(c, c->buckets, NB * 128))) return rc;
+  // reduction geometry: chunk = 64*L buckets per wave
+  int L = s.nb / 64; if (L > 8) L = 8; if (L < 1) L = 1;
+  int logL = 0; while ((1 << logL) < L) logL++;
+  const int chunks = s.nb / (64 * L);                     // per window, >= 1
+  if ((rc = ensure(c, c->red_a, (size_t)s.W * chunks * 256))) return rc;
+  if ((rc = ensure(c, c->red_b, (size_t)s.W * ((chunks + 63) / 64) * 256))) return rc;
+  if ((rc = ensure(c, c->wsum, (size_t)s.W * 128))) return rc;
+  if ((rc = ensure_pin(c, (size_t)s.W * 128))) return rc;
+
+  uint32_t* hist = (uint32_t*)c->hist.p; uint32_t* offs = (uint32_t*)c->offs.p; uint32_t* cursor = (uint32_t*)c->cursor.p;
+  uint32_t* sorted = (uint32_t*)c->sorted.p; uint32_t* buckets = (uint32_t*)c->buckets.p;
+
+  HIPCHK(c, hipMemsetAsync(hist, 0, NB * 4, c->stream));
+  const unsigned gn = (unsigned)((n + 255) / 256);
+  LAUNCH(c, "k_digits_hist", k_digits_hist, gn, 256, d_scal, n, s, hist);
+  LAUNCH(c, "k_scan", k_scan, s.W, 1024, hist, offs, cursor, s.nb);
+  LAUNCH(c, "k_scatter", k_scatter, gn, 256, d_scal, n, s, cursor, sorted);
+  LAUNCH(c, "k_bucket_acc", k_bucket_acc, (unsigned)((NB + 255) / 256), 256, d_bases, n, s, hist, offs, sorted, buckets);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(s.W * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
+  // combine levels until one result per window
+  uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
+  int G = chunks, logM = 6 + logL;
+  for (;;) {
+    int Gout = (G + 63) / 64;
+    int final = (Gout == 1);
+    LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(s.W * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    if (final) break;
+    std::swap(in, outb); G = Gout; logM += 6;
+  }
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, (size_t)s.W * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  // 254-doubling serial chain on the host
+  const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
+  sbn_host::Pt total = sbn_host::combine_windows(S, s.W, s.c);
+  sbn_host::to_affine_bytes(total, out_xy, out_is_inf);
+  return SBN_OK;
+}
+
+static int stage_scalars(sbn_ctx* c, const uint8_t* host_scalars, size_t n, uint32_t flags, const uint32_t** d_out) {
+  int rc;
+  if ((rc = ensure(c, c->stage_scal, n * 32))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->stage_scal.p, host_scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (flags & SBN_SCALARS_MONT) {
+    if ((rc = ensure(c, c->scal_canon, n * 32))) return rc;
+    LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((n + 255) / 256), 256, (const uint32_t*)c->stage_scal.p, (uint32_t*)c->scal_canon.p, n);
+    *d_out = (const uint32_t*)c->scal_canon.p;
+  } else *d_out = (const uint32_t*)c->stage_scal.p;
+  return SBN_OK;
+}
+static int canon_scalars_dev(sbn_ctx* c, const void* d_scalars, size_t n, uint32_t flags, const uint32_t** d_out) {
+  if (flags & SBN_SCALARS_MONT) {
+    int rc; if ((rc = ensure(c, c->scal_canon, n * 32))) return rc;
+    LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((n + 255) / 256), 256, (const uint32_t*)d_scalars, (uint32_t*)c->scal_canon.p, n);
+    *d_out = (const uint32_t*)c->scal_canon.p;
+  } else *d_out = (const uint32_t*)d_scalars;
+  return SBN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+const char* sbn_version(void) { return "sbn254-hip 0.1 (gfx950)"; }
+
+int sbn_ctx_create(int device, sbn_ctx** out) {
+  if (!out) return SBN_EINVAL;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SBN_ENODEV;
+  if (device < 0 || device >= count) return SBN_ENODEV;
+  if (hipSetDevice(device) != hipSuccess) return SBN_ENODEV;
+  sbn_ctx* c = new sbn_ctx();
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SBN_EHIP; }
+  c->stream = c->own_stream;
+  *out = c;
+  return SBN_OK;
+}
+void sbn_ctx_destroy(sbn_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  prof_drain(c);
+  DevBuf* bufs[] = {&c->scal_canon, &c->pts_mont, &c->hist, &c->offs, &c->cursor, &c->sorted, &c->buckets, &c->red_a, &c->red_b, &c->wsum, &c->stage_scal, &c->stage_pts, &c->out_small,
+                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  if (c->pin) hipHostFree(c->pin);
+  for (hipEvent_t e : c->evt_pool) hipEventDestroy(e);
+  hipStreamDestroy(c->own_stream);
+  delete c;
+}
+const char* sbn_last_error(const sbn_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int sbn_ctx_set_stream(sbn_ctx* c, void* s) { if (!c) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); c->stream = s ? (hipStream_t)s : c->own_stream; return SBN_OK; }
+int sbn_ctx_sync(sbn_ctx* c) { if (!c) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); HIPCHK(c, hipStreamSynchronize(c->stream)); if (c->prof) prof_drain(c); return SBN_OK; }
+
+int sbn_dev_alloc(sbn_ctx* c, size_t bytes, void** out) { if (!c || !out) return SBN_EINVAL; hipSetDevice(c->device); hipError_t e = hipMalloc(out, bytes ? bytes : 1); if (e != hipSuccess) return fail(c, SBN_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return SBN_OK; }
+int sbn_dev_free(sbn_ctx* c, void* p) { if (!c) return SBN_EINVAL; HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(p)); return SBN_OK; }
+int sbn_dev_upload(sbn_ctx* c, void* dst, const void* src, size_t bytes) { if (!c || (!dst && bytes) || (!src && bytes)) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return SBN_OK; }
+int sbn_dev_download(sbn_ctx* c, void* dst, const void* src, size_t bytes) { if (!c || (!dst && bytes) || (!src && bytes)) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); return SBN_OK; }
+
+int sbn_bases_upload(sbn_ctx* c, const uint8_t* G_xy, size_t n, const uint8_t* h_xy, uint32_t flags, sbn_bases** out) {
+  if (!c || !out || (!G_xy && n)) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const size_t tot = n + (h_xy ? 1 : 0);
+  sbn_bases* b = new sbn_bases(); b->n = n; b->has_h = h_xy != nullptr;
+  hipError_t e = hipMalloc(&b->d_pts, (tot ? tot : 1) * 64);
+  if (e != hipSuccess) { delete b; return fail(c, SBN_ENOMEM, "hipMalloc bases: %s", hipGetErrorString(e)); }
+  if (n) HIPCHK(c, hipMemcpyAsync(b->d_pts, G_xy, n * 64, hipMemcpyHostToDevice, c->stream));
+  if (h_xy) HIPCHK(c, hipMemcpyAsync((uint8_t*)b->d_pts + n * 64, h_xy, 64, hipMemcpyHostToDevice, c->stream));
+  if (!(flags & SBN_POINTS_MONT) && tot)
+    LAUNCH(c, "k_points_to_mont", k_points_to_mont, (unsigned)((tot + 255) / 256), 256, (const uint32_t*)b->d_pts, (uint32_t*)b->d_pts, tot);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = b;
+  return SBN_OK;
+}
+void sbn_bases_free(sbn_ctx* c, sbn_bases* b) { if (!b) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (b->d_pts) hipFree(b->d_pts); delete b; }
+size_t sbn_bases_len(const sbn_bases* b) { return b ? b->n : 0; }
+
+int sbn_msm_bases_dev(sbn_ctx* c, const sbn_bases* b, const void* d_scalars, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
+  if (!c || !b || !out_xy || (!d_scalars && n)) return SBN_EINVAL;
+  if (n > b->n + (b->has_h ? 1 : 0)) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds the table (%zu)", n, b->n + (b->has_h ? 1 : 0));
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const uint32_t* ds; int rc;
+  if ((rc = canon_scalars_dev(c, d_scalars, n, flags, &ds))) return rc;
+  return msm_device(c, ds, (const uint32_t*)b->d_pts, n, out_xy, out_is_inf);
+}
+int sbn_msm_bases(sbn_ctx* c, const sbn_bases* b, const uint8_t* scalars, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
+  if (!c || !b || !out_xy || (!scalars && n)) return SBN_EINVAL;
+  if (n > b->n + (b->has_h ? 1 : 0)) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds the table (%zu)", n, b->n + (b->has_h ? 1 : 0));
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  const uint32_t* ds; int rc;
+  if ((rc = stage_scalars(c, scalars, n, flags, &ds))) return rc;
+  return msm_device(c, ds, (const uint32_t*)b->d_pts, n, out_xy, out_is_inf);
+}
+int sbn_msm(sbn_ctx* c, const uint8_t* scalars, const uint8_t* points, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
+  if (!c || !out_xy || ((!scalars || !points) && n)) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  int rc; const uint32_t* ds;
+  if ((rc = stage_scalars(c, scalars, n, flags, &ds))) return rc;
+  if ((rc = ensure(c, c->stage_pts, n * 64))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->stage_pts.p, points, n * 64, hipMemcpyHostToDevice, c->stream));
+  if (!(flags & SBN_POINTS_MONT))
+    LAUNCH(c, "k_points_to_mont", k_points_to_mont, (unsigned)((n + 255) / 256), 256, (const uint32_t*)c->stage_pts.p, (uint32_t*)c->stage_pts.p, n);
+  return msm_device(c, ds, (const uint32_t*)c->stage_pts.p, n, out_xy, out_is_inf);
+}
+
+// v1: one MSM per row (correct for every shape; the batched shared-base kernels replace this loop)
+int sbn_commit_rows_dev(sbn_ctx* c, const sbn_bases* b, const void* Z_dev, const void* blinds_dev, size_t L, size_t R, uint32_t flags, uint8_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || !out_xy || (!Z_dev && L * R)) return SBN_EINVAL;
+  if (R != b->n) return fail(c, SBN_EINVAL, "commit: gens_n.n (%zu) != row length (%zu)  [commitments.rs:146 assert_eq]", b->n, R);
+  if (blinds_dev && !b->has_h) return fail(c, SBN_EINVAL, "commit: blinds given but the table has no h");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  int rc;
+  const size_t n1 = R + (blinds_dev ? 1 : 0);
+  if ((rc = ensure(c, c->out_small, n1 * 32))) return rc;
+  for (size_t i = 0; i < L; i++) {
+    // row scalars || blind, contiguous, canonical
+    uint8_t* row = (uint8_t*)c->out_small.p;
+    HIPCHK(c, hipMemcpyAsync(row, (const uint8_t*)Z_dev + i * R * 32, R * 32, hipMemcpyDeviceToDevice, c->stream));
+    if (blinds_dev) HIPCHK(c, hipMemcpyAsync(row + R * 32, (const uint8_t*)blinds_dev + i * 32, 32, hipMemcpyDeviceToDevice, c->stream));
+    const uint32_t* ds;
+    if ((rc = canon_scalars_dev(c, row, n1, flags, &ds))) return rc;
+    int inf = 0;
+    if ((rc = msm_device(c, ds, (const uint32_t*)b->d_pts, n1, out_xy + 64 * i, &inf))) return rc;
+    if (out_inf) out_inf[i] = (uint8_t)inf;
+  }
+  return SBN_OK;
+}
+int sbn_commit_rows(sbn_ctx* c, const sbn_bases* b, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R, uint32_t flags, uint8_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || !out_xy || (!Z && L * R)) return SBN_EINVAL;
+  void* dZ = nullptr; void* dB = nullptr; int rc;
+  if ((rc = sbn_dev_alloc(c, L * R * 32, &dZ))) return rc;
+  if ((rc = sbn_dev_upload(c, dZ, Z, L * R * 32))) { sbn_dev_free(c, dZ); return rc; }
+  if (blinds) {
+    if ((rc = sbn_dev_alloc(c, L * 32, &dB))) { sbn_dev_free(c, dZ); return rc; }
+    if ((rc = sbn_dev_upload(c, dB, blinds, L * 32))) { sbn_dev_free(c, dZ); sbn_dev_free(c, dB); return rc; }
+  }
+  rc = sbn_commit_rows_dev(c, b, dZ, dB, L, R, flags, out_xy, out_inf);
+  sbn_dev_free(c, dZ); if (dB) sbn_dev_free(c, dB);
+  return rc;
+}
+
+int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32) {
+  if ((!xy || !out32) && n) return SBN_EINVAL;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* p = xy + 64 * i; uint8_t* o = out32 + 32 * i;
+    bool inf = true; for (int k = 0; k < 64; k++) if (p[k]) { inf = false; break; }
+    if (inf) { memset(o, 0, 32); o[31] = 0x40; continue; }
+    memcpy(o, p, 32);
+    // y > p - y  <=>  2y > p
+    uint64_t y[4], t[4]; memcpy(y, p + 32, 32);
+    uint64_t cy = 0; for (int k = 0; k < 4; k++) { t[k] = (y[k] << 1) | cy; cy = y[k] >> 63; }
+    bool gt = cy != 0;
+    if (!gt) { gt = false; for (int k = 3; k >= 0; k--) { if (t[k] > sbn_host::QP[k]) { gt = true; break; } if (t[k] < sbn_host::QP[k]) break; } }
+    if (gt) o[31] |= 0x80;
+  }
+  return SBN_OK;
+}
+void sbn_factored_lens(size_t ell, size_t* left, size_t* right) { if (left) *left = ell / 2; if (right) *right = ell - ell / 2; }
+
+// ---- generators: MultiCommitGens::new (commitments.rs:31-62) ----
+static const uint64_t FR_MOD[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static bool fr_canonical(const uint8_t b[32]) {
+  uint64_t v[4]; memcpy(v, b, 32);
+  for (int i = 3; i >= 0; i--) { if (v[i] < FR_MOD[i]) return true; if (v[i] > FR_MOD[i]) return false; }
+  return false;
+}
+// GroupElement::from_uniform_bytes (group.rs:110-131): the scalar s with point = s*G
+static void uniform_bytes_scalar(const uint8_t ub[64], uint8_t s[32]) {
+  sbn_host::sha3_256(ub, 64, s);
+  if (fr_canonical(s)) return;                 // Scalar::from_bytes accepts only < r (scalar.rs:87-95)
+  uint8_t tmp[72]; memcpy(tmp, "fallback", 8); memcpy(tmp + 8, ub, 64);
+  sbn_host::sha3_256(tmp, 72, s);
+  if (fr_canonical(s)) return;
+  memset(s, 0, 32); s[0] = 1;                  // unwrap_or(Scalar::one())
+}
+int sbn_gens_new(sbn_ctx* c, size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, sbn_bases** out) {
+  if (!c || !out || (!label && label_len)) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const size_t tot = n + 1;
+  // SHAKE256(label || compressed generator); the generator (1,2) compresses to 01 00..00 (y = 2 is the smaller root)
+  uint8_t gc[32] = {1};
+  sbn_host::Keccak xof(136, 0x1f);
+  xof.absorb(label, label_len); xof.absorb(gc, 32);
+  std::vector<uint8_t> dl(tot * 32);
+  for (size_t i = 0; i < tot; i++) { uint8_t ub[64]; xof.squeeze(ub, 64); uniform_bytes_scalar(ub, &dl[32 * i]); }
+  int rc;
+  if ((rc = ensure(c, c->gen_tmp, tot * (32 + 128)))) return rc;
+  uint8_t* d_s = (uint8_t*)c->gen_tmp.p; uint8_t* d_x = d_s + tot * 32;
+  HIPCHK(c, hipMemcpyAsync(d_s, dl.data(), tot * 32, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_mul_generator", k_mul_generator, (unsigned)((tot + 63) / 64), 64, (const uint32_t*)d_s, tot, (uint32_t*)d_x);
+  sbn_bases* b = new sbn_bases(); b->n = n; b->has_h = true;
+  hipError_t e = hipMalloc(&b->d_pts, tot * 64);
+  if (e != hipSuccess) { delete b; return fail(c, SBN_ENOMEM, "hipMalloc gens: %s", hipGetErrorString(e)); }
+  uint32_t* d_xy = nullptr;
+  if (out_xy) { if ((rc = ensure(c, c->out_small, tot * 64))) { hipFree(b->d_pts); delete b; return rc; } d_xy = (uint32_t*)c->out_small.p; }
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((tot + 63) / 64), 64, (const uint32_t*)d_x, (uint32_t*)b->d_pts, d_xy, (uint8_t*)nullptr, tot);
+  LAUNCHCHK(c);
+  if (out_xy) HIPCHK(c, hipMemcpyAsync(out_xy, d_xy, tot * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = b;
+  return SBN_OK;
+}
+
+// ---- tables + sumcheck rounds ----
+static unsigned stream_grid(size_t work_items) {
+  size_t blocks = (work_items + 255) / 256;
+  if (blocks > 2048) blocks = 2048;     // 256 CUs x 8 blocks, grid-stride beyond
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+static int table_make(sbn_ctx* c, const void* src, bool src_is_host, size_t len, uint32_t flags, sbn_table** out) {
+  if (len == 0 || (len & (len - 1))) return fail(c, SBN_EINVAL, "table length %zu is not a power of two", len);
+  sbn_table* t = new sbn_table(); t->len = len; t->cap = len;
+  hipError_t e = hipMalloc(&t->d, len * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc table: %s", hipGetErrorString(e)); }
+  HIPCHK(c, hipMemcpyAsync(t->d, src, len * 32, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+  if (!(flags & SBN_SCALARS_MONT)) LAUNCH(c, "k_fr_to_mont", k_fr_to_mont, stream_grid(len), 256, (const uint32_t*)t->d, (uint32_t*)t->d, len);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = t;
+  return SBN_OK;
+}
+int sbn_table_upload(sbn_ctx* c, const uint8_t* Z, size_t len, uint32_t flags, sbn_table** out) {
+  if (!c || !Z || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  return table_make(c, Z, true, len, flags, out);
+}
+int sbn_table_from_dev(sbn_ctx* c, const void* Z_dev, size_t len, uint32_t flags, sbn_table** out) {
+  if (!c || !Z_dev || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  return table_make(c, Z_dev, false, len, flags, out);
+}
+void sbn_table_free(sbn_ctx* c, sbn_table* t) { if (!t) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (t->d && t->owned) hipFree(t->d); delete t; }
+size_t sbn_table_len(const sbn_table* t) { return t ? t->len : 0; }
+int sbn_table_download(sbn_ctx* c, const sbn_table* t, uint8_t* out) {
+  if (!c || !t || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  int rc; if ((rc = ensure(c, c->stage_scal, t->len * 32))) return rc;
+  LAUNCH(c, "k_fr_from_mont", k_fr_from_mont, stream_grid(t->len), 256, (const uint32_t*)t->d, (uint32_t*)c->stage_scal.p, t->len);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, c->stage_scal.p, t->len * 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SBN_OK;
+}
+int sbn_table_read0(sbn_ctx* c, const sbn_table* t, uint8_t out[32]) {
+  if (!c || !t || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  int rc; if ((rc = ensure(c, c->sc_out, 4096))) return rc;
+  LAUNCH(c, "k_fr_from_mont", k_fr_from_mont, 1, 256, (const uint32_t*)t->d, (uint32_t*)c->sc_out.p, (size_t)1);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out, c->sc_out.p, 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return SBN_OK;
+}
+static int upload_r_mont(sbn_ctx* c, const uint8_t r[32]) {
+  int rc; if ((rc = ensure(c, c->sc_r, 64))) return rc;
+  if ((rc = ensure_pin(c, 4096))) return rc;
+  if (!fr_canonical(r)) return fail(c, SBN_EINVAL, "challenge scalar is not canonical (>= r)");
+  memcpy(c->pin, r, 32);
+  HIPCHK(c, hipMemcpyAsync(c->sc_r.p, c->pin, 32, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_fr_to_mont", k_fr_to_mont, 1, 256, (const uint32_t*)c->sc_r.p, (uint32_t*)c->sc_r.p, (size_t)1);
+  return SBN_OK;
+}
+int sbn_bind_top_many(sbn_ctx* c, sbn_table* const* ts, size_t count, const uint8_t r[32]) {
+  if (!c || !ts || !r || count == 0) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  for (size_t i = 0; i < count; i++) { if (!ts[i]) return SBN_EINVAL; if (ts[i]->len != ts[0]->len) return fail(c, SBN_EINVAL, "bind: tables differ in length"); }
+  if (ts[0]->len < 2) return fail(c, SBN_EINVAL, "bind: table has no variable left");
+  int rc; if ((rc = upload_r_mont(c, r))) return rc;
+  if ((rc = ensure(c, c->sc_tabs, count * sizeof(void*)))) return rc;
+  // pinned staging lives after the 32-byte r slot
+  if ((rc = ensure_pin(c, 4096 + count * sizeof(void*)))) return rc;
+  void** hp = (void**)((uint8_t*)c->pin + 64);
+  for (size_t i = 0; i < count; i++) hp[i] = ts[i]->d;
+  HIPCHK(c, hipMemcpyAsync(c->sc_tabs.p, hp, count * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+  const size_t half = ts[0]->len / 2;
+  unsigned gx = stream_grid(half); if (count > 1 && gx > 1024) gx = 1024;
+  LAUNCH(c, "k_bind_top", k_bind_top, dim3(gx, (unsigned)count), 256, (uint32_t* const*)c->sc_tabs.p, half, (const uint32_t*)c->sc_r.p);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));      // the pinned staging is reused by the next call
+  if (c->prof) prof_drain(c);
+  for (size_t i = 0; i < count; i++) ts[i]->len = half;
+  return SBN_OK;
+}
+int sbn_bind_top(sbn_ctx* c, sbn_table* t, const uint8_t r[32]) { sbn_table* one[1] = {t}; return sbn_bind_top_many(c, one, 1, r); }
+
+}  // extern "C" (templates need C++ linkage)
+template <int KIND>
+static int sc_eval_common(sbn_ctx* c, const sbn_table* const* const* cols, int ncols, size_t count, uint8_t* out) {
+  // cols[j][i] = table j of instance i
+  const size_t len = cols[0][0]->len;
+  for (int j = 0; j < ncols; j++) for (size_t i = 0; i < count; i++) {
+    if (!cols[j][i]) return SBN_EINVAL;
+    if (cols[j][i]->len != len) return fail(c, SBN_EINVAL, "sumcheck eval: tables differ in length");
+  }
+  if (len < 2) return fail(c, SBN_EINVAL, "sumcheck eval: no variable left");
+  const size_t half = len / 2;
+  int rc;
+  if ((rc = ensure(c, c->sc_args, count * sizeof(ScArgs)))) return rc;
+  if ((rc = ensure_pin(c, 4096 + count * sizeof(ScArgs) + count * 96))) return rc;
+  ScArgs* ha = (ScArgs*)((uint8_t*)c->pin + 64);
+  for (size_t i = 0; i < count; i++) for (int j = 0; j < 4; j++) ha[i].t[j] = j < ncols ? (const uint32_t*)cols[j][i]->d : nullptr;
+  HIPCHK(c, hipMemcpyAsync(c->sc_args.p, ha, count * sizeof(ScArgs), hipMemcpyHostToDevice, c->stream));
+  unsigned gx = stream_grid(half); if (gx > 1024) gx = 1024;
+  if ((rc = ensure(c, c->sc_partial, (size_t)count * gx * 96))) return rc;
+  if ((rc = ensure(c, c->sc_out, std::max<size_t>(4096, count * 96)))) return rc;
+  const char* nm = KIND == KIND_CUBIC ? "k_sc_eval_cubic" : KIND == KIND_R1CS ? "k_sc_eval_r1cs" : "k_sc_eval_quad";
+  LAUNCH(c, nm, k_sc_eval<KIND>, dim3(gx, (unsigned)count), 256, (const ScArgs*)c->sc_args.p, half, (uint32_t*)c->sc_partial.p);
+  LAUNCH(c, "k_sc_finish", k_sc_finish, (unsigned)count, 64, (const uint32_t*)c->sc_partial.p, (int)gx, (uint32_t*)c->sc_out.p);
+  LAUNCHCHK(c);
+  uint8_t* hres = (uint8_t*)c->pin + 64 + count * sizeof(ScArgs);
+  HIPCHK(c, hipMemcpyAsync(hres, c->sc_out.p, count * 96, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  if (KIND == KIND_QUAD) { for (size_t i = 0; i < count; i++) memcpy(out + 64 * i, hres + 96 * i, 64); }
+  else memcpy(out, hres, count * 96);
+  return SBN_OK;
+}
+extern "C" {
+int sbn_sc_eval_cubic_batched(sbn_ctx* c, const sbn_table* const* A, const sbn_table* const* B, const sbn_table* const* Cc, size_t count, uint8_t* out) {
+  if (!c || !A || !B || !Cc || !out || count == 0) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  const sbn_table* const* cols[3] = {A, B, Cc};
+  return sc_eval_common<KIND_CUBIC>(c, cols, 3, count, out);
+}
+int sbn_sc_eval_cubic(sbn_ctx* c, const sbn_table* A, const sbn_table* B, const sbn_table* Cc, uint8_t out[96]) {
+  if (!A || !B || !Cc) return SBN_EINVAL;
+  return sbn_sc_eval_cubic_batched(c, &A, &B, &Cc, 1, out);
+}
+int sbn_sc_eval_r1cs(sbn_ctx* c, const sbn_table* T, const sbn_table* A, const sbn_table* B, const sbn_table* Cc, uint8_t out[96]) {
+  if (!c || !T || !A || !B || !Cc || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  const sbn_table* const* cols[4] = {&T, &A, &B, &Cc};
+  return sc_eval_common<KIND_R1CS>(c, cols, 4, 1, out);
+}
+int sbn_sc_eval_quad(sbn_ctx* c, const sbn_table* Z, const sbn_table* ABC, uint8_t out[64]) {
+  if (!c || !Z || !ABC || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  const sbn_table* const* cols[2] = {&Z, &ABC};
+  return sc_eval_common<KIND_QUAD>(c, cols, 2, 1, out);
+}
+int sbn_eq_evals(sbn_ctx* c, const uint8_t* r, size_t ell, sbn_table** out) {
+  if (!c || (!r && ell) || !out || ell > 40) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  for (size_t j = 0; j < ell; j++) if (!fr_canonical(r + 32 * j)) return fail(c, SBN_EINVAL, "eq_evals: r[%zu] is not canonical", j);
+  const size_t N = (size_t)1 << ell;
+  int rc;
+  if ((rc = ensure(c, c->stage_scal, std::max<size_t>(N * 32, 64)))) return rc;     // ping-pong partner
+  if ((rc = ensure(c, c->sc_r, std::max<size_t>(64, ell * 32)))) return rc;
+  sbn_table* t = new sbn_table(); t->len = N; t->cap = N;
+  hipError_t e = hipMalloc(&t->d, N * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc eq table: %s", hipGetErrorString(e)); }
+  if (ell) {
+    HIPCHK(c, hipMemcpyAsync(c->sc_r.p, r, ell * 32, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "k_fr_to_mont", k_fr_to_mont, 1, 256, (const uint32_t*)c->sc_r.p, (uint32_t*)c->sc_r.p, ell);
+  }
+  // ping-pong so that the last level lands in t->d
+  uint32_t* bufA = (uint32_t*)t->d; uint32_t* bufB = (uint32_t*)c->stage_scal.p;
+  uint32_t* cur = (ell % 2 == 0) ? bufA : bufB;
+  LAUNCH(c, "k_fr_set_one", k_fr_set_one, 1, 64, cur);
+  size_t size = 1;
+  for (size_t j = 0; j < ell; j++) {
+    uint32_t* nxt = (cur == bufA) ? bufB : bufA;
+    LAUNCH(c, "k_eq_level", k_eq_level, stream_grid(size), 256, (const uint32_t*)cur, nxt, size, (const uint32_t*)c->sc_r.p + 8 * j);
+    cur = nxt; size *= 2;
+  }
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = t;
+  return SBN_OK;
+}
+
+int sbn_prof_enable(sbn_ctx* c, int on) { if (!c) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); c->prof = on != 0; return SBN_OK; }
+int sbn_prof_reset(sbn_ctx* c) { if (!c) return SBN_EINVAL; std::lock_guard<std::mutex> g(c->mu); hipStreamSynchronize(c->stream); prof_drain(c); c->prof_entries.clear(); return SBN_OK; }
+int sbn_prof_count(sbn_ctx* c) { if (!c) return 0; std::lock_guard<std::mutex> g(c->mu); hipStreamSynchronize(c->stream); prof_drain(c); return (int)c->prof_entries.size(); }
+int sbn_prof_get(sbn_ctx* c, int i, const char** name, double* total_ms, uint64_t* launches) {
+  if (!c || i < 0 || (size_t)i >= c->prof_entries.size()) return SBN_EINVAL;
+  if (name) *name = c->prof_entries[i].name.c_str();
+  if (total_ms) *total_ms = c->prof_entries[i].ms;
+  if (launches) *launches = c->prof_entries[i].launches;
+  return SBN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,134 @@
+// sumcheck_kernels.cuh — per-round multilinear evaluations and the top-variable bind, over BN254 Fr.
+//
+// Reference loops replaced (all serial `for i in 0..len` loops over Vec<Scalar> there):
+//   prove_cubic                     src/sumcheck.rs:111-135   f = A*B*C            -> k_sc_eval<KIND_CUBIC>
+//   prove_cubic_batched             src/sumcheck.rs:201-267   same, many instances  -> grid.y = instance
+//   prove_cubic_with_additive_term  src/sumcheck.rs:502-530   f = T*(A*B - C)       -> k_sc_eval<KIND_R1CS>
+//   prove_quad                      src/sumcheck.rs:691-699   f = Z*ABC (pts 0,2)   -> k_sc_eval<KIND_QUAD>
+//   bound_poly_var_top              src/hyrax.rs:195-203      Z[i] += r*(Z[i+n]-Z[i]) -> k_bind_top
+//   EqPolynomial::evals             src/hyrax.rs:355-369                              -> k_eq_level
+// Evaluation points follow the reference exactly: p(2) = 2*hi - lo, p(3) = p(2) + hi - lo, and the host
+// receives (e0, e2, e3) — e1 is derived from the claim on the host (sumcheck.rs:137).
+//
+// Tables are AoS arrays of 32-byte Montgomery-form elements; lane i reads element i with two 16-byte loads, so
+// a wavefront reads 2 KiB contiguous per table half — the kernels are HBM-streaming with ~1 product per 32 B.
+// Field addition is associative and commutative mod r, so the tree-shaped partial sums give the same canonical
+// result as the reference's left-to-right loop.
+#pragma once
+#include "fp.cuh"
+
+namespace sbn {
+
+enum { KIND_CUBIC = 0, KIND_R1CS = 1, KIND_QUAD = 2 };
+
+struct ScArgs {          // one instance: up to 4 tables, all of length 2*half
+  const uint32_t* t[4];
+};
+
+__device__ __forceinline__ Fr wave_sum_fr(Fr v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(v.v[i], d, 64);
+    v = fe_add(v, o);
+  }
+  return v;
+}
+
+// partial[inst][block][3] (Montgomery form)
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args, size_t half, uint32_t* __restrict__ partial) {
+  const ScArgs a = args[blockIdx.y];
+  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    if (KIND == KIND_QUAD) {
+      Fr zl = fe_load<FrP>(a.t[0] + 8 * i), zh = fe_load<FrP>(a.t[0] + 8 * (i + half));
+      Fr al = fe_load<FrP>(a.t[1] + 8 * i), ah = fe_load<FrP>(a.t[1] + 8 * (i + half));
+      e0 = fe_add(e0, fe_mul(zl, al));
+      Fr z2 = fe_sub(fe_dbl(zh), zl), a2 = fe_sub(fe_dbl(ah), al);
+      e2 = fe_add(e2, fe_mul(z2, a2));
+    } else if (KIND == KIND_CUBIC) {
+      Fr al = fe_load<FrP>(a.t[0] + 8 * i), ah = fe_load<FrP>(a.t[0] + 8 * (i + half));
+      Fr bl = fe_load<FrP>(a.t[1] + 8 * i), bh = fe_load<FrP>(a.t[1] + 8 * (i + half));
+      Fr cl = fe_load<FrP>(a.t[2] + 8 * i), ch = fe_load<FrP>(a.t[2] + 8 * (i + half));
+      e0 = fe_add(e0, fe_mul(fe_mul(al, bl), cl));
+      Fr da = fe_sub(ah, al), db = fe_sub(bh, bl), dc = fe_sub(ch, cl);
+      Fr a2 = fe_add(ah, da), b2 = fe_add(bh, db), c2 = fe_add(ch, dc);        // 2*hi - lo
+      e2 = fe_add(e2, fe_mul(fe_mul(a2, b2), c2));
+      Fr a3 = fe_add(a2, da), b3 = fe_add(b2, db), c3 = fe_add(c2, dc);        // p(2) + hi - lo
+      e3 = fe_add(e3, fe_mul(fe_mul(a3, b3), c3));
+    } else {
+      Fr tl = fe_load<FrP>(a.t[0] + 8 * i), th = fe_load<FrP>(a.t[0] + 8 * (i + half));
+      Fr al = fe_load<FrP>(a.t[1] + 8 * i), ah = fe_load<FrP>(a.t[1] + 8 * (i + half));
+      Fr bl = fe_load<FrP>(a.t[2] + 8 * i), bh = fe_load<FrP>(a.t[2] + 8 * (i + half));
+      Fr cl = fe_load<FrP>(a.t[3] + 8 * i), ch = fe_load<FrP>(a.t[3] + 8 * (i + half));
+      e0 = fe_add(e0, fe_mul(tl, fe_sub(fe_mul(al, bl), cl)));
+      Fr dt = fe_sub(th, tl), da = fe_sub(ah, al), db = fe_sub(bh, bl), dc = fe_sub(ch, cl);
+      Fr t2 = fe_add(th, dt), a2 = fe_add(ah, da), b2 = fe_add(bh, db), c2 = fe_add(ch, dc);
+      e2 = fe_add(e2, fe_mul(t2, fe_sub(fe_mul(a2, b2), c2)));
+      Fr t3 = fe_add(t2, dt), a3 = fe_add(a2, da), b3 = fe_add(b2, db), c3 = fe_add(c2, dc);
+      e3 = fe_add(e3, fe_mul(t3, fe_sub(fe_mul(a3, b3), c3)));
+    }
+  }
+  // block reduction: wave shuffles, then LDS across the 4 waves
+  __shared__ uint32_t sm[4][3][8];
+  e0 = wave_sum_fr(e0); e2 = wave_sum_fr(e2);
+  if (KIND != KIND_QUAD) e3 = wave_sum_fr(e3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
+    uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x);
+    for (int k = 0; k < 8; k++) o[k] = s.v[k];
+  }
+}
+
+// out[inst][3] canonical; one 64-lane block per instance folds `nblk` partial triples
+__global__ void __launch_bounds__(64) k_sc_finish(const uint32_t* __restrict__ partial, int nblk, uint32_t* __restrict__ out) {
+  const int inst = blockIdx.x, lane = threadIdx.x;
+  for (int q = 0; q < 3; q++) {
+    Fr s = fe_zero<FrP>();
+    for (int b = lane; b < nblk; b += 64) { Fr x = fe_load<FrP>(partial + 8 * (((size_t)inst * nblk + b) * 3 + q)); s = fe_add(s, x); }
+    s = wave_sum_fr(s);
+    if (lane == 0) fe_store<FrP>(out + 8 * ((size_t)inst * 3 + q), fe_from_mont(s));
+  }
+}
+
+// bind the top variable of up to `count` tables (blockIdx.y = table) to r (Montgomery form, in `rm`)
+__global__ void __launch_bounds__(256) k_bind_top(uint32_t* const* __restrict__ tabs, size_t half, const uint32_t* __restrict__ rm) {
+  uint32_t* Z = tabs[blockIdx.y];
+  const Fr r = fe_load<FrP>(rm);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
+    fe_store<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
+  }
+}
+
+__global__ void __launch_bounds__(256) k_fr_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fe_store<FrP>(out + 8 * i, fe_to_mont(fe_load<FrP>(in + 8 * i)));
+}
+__global__ void __launch_bounds__(256) k_fr_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    fe_store<FrP>(out + 8 * i, fe_from_mont(fe_load<FrP>(in + 8 * i)));
+}
+
+// one level of EqPolynomial::evals: out[2k+1] = in[k]*r_j ; out[2k] = in[k] - out[2k+1]   (hyrax.rs:360-366)
+__global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, const uint32_t* __restrict__ rj_mont) {
+  const Fr r = fe_load<FrP>(rj_mont);
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < size_in; k += (size_t)gridDim.x * blockDim.x) {
+    Fr s = fe_load<FrP>(in + 8 * k);
+    Fr hi = fe_mul(s, r);
+    fe_store<FrP>(out + 8 * (2 * k + 1), hi);
+    fe_store<FrP>(out + 8 * (2 * k), fe_sub(s, hi));
+  }
+}
+__global__ void k_fr_set_one(uint32_t* out) { if (threadIdx.x == 0 && blockIdx.x == 0) fe_store<FrP>(out, fe_one<FrP>()); }
+
+}  // namespace sbn
