@@ -69,6 +69,12 @@ size_t sbn_bases_len(const sbn_bases* b);          /* n (without h) */
  * builds G[0..n) and h on the device and, if out_xy != NULL, also returns the n+1 canonical points. */
 int sbn_gens_new(sbn_ctx* ctx, size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, sbn_bases** out);
 
+/* Synthetic benchmark bases with known discrete logs: P_i = (s0 + (first + i) * d) * G for
+ * i in [0, n), all distinct, built on the device; the expected MSM result is then (sum k_i (s0 + (first+i) d)) * G. */
+int sbn_bases_synthetic(sbn_ctx* ctx, size_t n, uint64_t first, const uint8_t s0[32], const uint8_t d[32], sbn_bases** out);
+/* copy `count` points starting at `first` back to the host as canonical x||y (for tests of resident tables) */
+int sbn_bases_download(sbn_ctx* ctx, const sbn_bases* b, size_t first, size_t count, uint8_t* out_xy);
+
 /* MSM of n scalars against the first n points of a resident table (no h): msm_affine with cached G_affine */
 int sbn_msm_bases(sbn_ctx* ctx, const sbn_bases* b, const uint8_t* scalars, size_t n, uint32_t flags,
                   uint8_t out_xy[64], int* out_is_inf);
@@ -87,6 +93,9 @@ int sbn_commit_rows_dev(sbn_ctx* ctx, const sbn_bases* b, const void* Z_dev, con
                         uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
 /* arkworks serialize_compressed of n affine points (group.rs:135-140; what transcript.rs:102-108 absorbs) */
 int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32);
+/* sum of n canonical affine points on the host (no device needed): the fold of per-GPU partial MSM results after
+ * the RCCL all-gather, i.e. the `+` of GroupElement (group.rs:199-262) applied n-1 times */
+int sbn_g1_sum(const uint8_t* xy, size_t n, uint8_t out_xy[64], int* out_is_inf);
 /* EqPolynomial::compute_factored_lens (hyrax.rs:371-373) */
 void sbn_factored_lens(size_t ell, size_t* left, size_t* right);
 

@@ -10,8 +10,8 @@ SBN_POINTS_MONT = 2
 EXPORTED_SYMBOLS = [
     "sbn_ctx_create", "sbn_ctx_destroy", "sbn_last_error", "sbn_ctx_set_stream", "sbn_ctx_sync", "sbn_version",
     "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
-    "sbn_msm", "sbn_bases_upload", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new",
-    "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_factored_lens",
+    "sbn_msm", "sbn_bases_upload", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_bases_download",
+    "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_factored_lens",
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_eq_evals", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
@@ -38,6 +38,13 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
+        # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7, like /opt/rocm's).  Import it FIRST so that this
+        # library binds to the HIP runtime torch already loaded; the other order puts two runtimes in one process and
+        # the second one finds no GPU.  Without torch (the Rust shim) /opt/rocm's runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         p = lib_path()
         if not os.path.exists(p):
             raise SbnError(f"{p} is missing: run `make -C {_HERE}` (or __graft_entry__.build()); there is no CPU fallback")
@@ -74,6 +81,16 @@ def g1_compress(xy):
     if rc:
         raise SbnError(f"sbn_g1_compress rc={rc}")
     return bytes(out)
+
+
+def g1_sum(xy):
+    """host-side sum of canonical affine points (the fold after the all-gather of per-GPU partials)"""
+    n = len(xy) // 64
+    out = (C.c_uint8 * 64)(); inf = C.c_int()
+    rc = lib().sbn_g1_sum(_ptr(xy), C.c_size_t(n), out, C.byref(inf))
+    if rc:
+        raise SbnError(f"sbn_g1_sum rc={rc}")
+    return bytes(out), bool(inf.value)
 
 
 def factored_lens(ell):
@@ -155,6 +172,16 @@ class Context:
         out = (C.c_uint8 * (64 * (n + 1)))() if want_points else None
         self._chk(lib().sbn_gens_new(self.h, C.c_size_t(n), _ptr(label), C.c_size_t(len(label)), out, C.byref(hb)), "sbn_gens_new")
         return Bases(self, hb), (bytes(out) if want_points else None)
+
+    def bases_synthetic(self, n, first, s0, d):
+        hb = C.c_void_p()
+        self._chk(lib().sbn_bases_synthetic(self.h, C.c_size_t(n), C.c_uint64(first), _ptr(s0), _ptr(d), C.byref(hb)), "sbn_bases_synthetic")
+        return Bases(self, hb)
+
+    def bases_download(self, bases, first, count):
+        out = (C.c_uint8 * (64 * count))()
+        self._chk(lib().sbn_bases_download(self.h, bases.h, C.c_size_t(first), C.c_size_t(count), out), "sbn_bases_download")
+        return bytes(out)
 
     def msm_bases(self, bases, scalars, flags=0):
         n = len(scalars) // 32

@@ -4,11 +4,11 @@
 // commitments.rs:144-154 and hyrax.rs:253-267).  The algorithm is the bucket method but laid out
 // for a 256-CU wave64 machine instead of one CPU thread per window:
 //
-//   1. k_digits_hist   one thread per scalar: signed radix-2^c digits, histogram of bucket sizes
-//   2. k_scan          exclusive scan of the histogram per window (bucket start offsets)
-//   3. k_scatter       counting sort: point indices grouped by (window, bucket), sign in bit 31
-//   4. k_bucket_acc    one LANE per (window, bucket): XYZZ accumulator in VGPRs, affine points gathered
-//                      from HBM (64 B each), no atomics on points, no inter-lane traffic
+//   1. k_digits<hist>  one thread per scalar: signed radix-2^c digits, histogram of bucket sizes
+//   2. k_scan          exclusive scan of the histogram per problem (bucket start offsets)
+//   3. k_digits<scat>  counting sort: point indices grouped by (problem, bucket), sign in bit 31
+//   4. k_acc_*         one LANE per bucket: XYZZ accumulator in VGPRs, affine points gathered from HBM (64 B
+//                      each), no atomics on points; oversized buckets are cut into segments (k_acc_extra/merge)
 //   5. k_reduce_l1 / k_reduce_combine   sum_b (b+1)*B_b per window: lane-sequential running sums over L buckets, then a
 //                      wave-level suffix scan + tree (DPP/LDS-free __shfl) — log-depth instead of the
 //                      reference's 2^c-long serial chain
@@ -56,24 +56,56 @@ __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restri
   fe_store<FqP>(out + 16 * i + 8, fe_to_mont(y));
 }
 
-// 1. histogram.  `stride` = distance in scalars between rows' scalars (single MSM: rows = 1).
-__global__ void __launch_bounds__(256) k_digits_hist(const uint32_t* __restrict__ scalars, size_t n, MsmShape s, uint32_t* __restrict__ hist) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* k = scalars + 8 * i;
+// ---- digit extraction / counting sort ----------------------------------------------------------
+// Two front-ends share every later stage.  A "problem" owns nb buckets and produces one weighted bucket sum:
+//   MODE_SINGLE  one MSM of n terms: problem = window w (W problems); entry = point index
+//   MODE_ROWS    Hyrax row commits over shared bases (hyrax.rs:253-267): problem = matrix row (L problems); all W
+//                windows of a row share ONE bucket set because the table holds 2^(c*w)*G_j for every window w
+//                (entry = w*tstride + column), so no doublings are needed after the bucket sum.
+enum { MODE_SINGLE = 0, MODE_ROWS = 1 };
+struct DigitArgs {
+  const uint32_t* scalars;   // SINGLE: n x 8 limbs.  ROWS: L x R x 8, row-major
+  const uint32_t* blinds;    // ROWS: L x 8 or null (null = zero blinds, hyrax.rs:301-305)
+  size_t n;                  // SINGLE: number of scalars.  ROWS: columns per row incl. the blind column if present
+  size_t R;                  // ROWS: row length of Z
+  size_t L;                  // ROWS: number of rows
+  size_t tstride;            // ROWS: points per window slab of the table
+  size_t estride;            // sorted-entry capacity per problem
+};
+
+template <int MODE, bool SCATTER>
+__global__ void __launch_bounds__(256) k_digits(DigitArgs a, MsmShape s, uint32_t* __restrict__ hist_or_cursor, uint32_t* __restrict__ sorted) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* k; size_t row = 0, col = 0;
+  if (MODE == MODE_SINGLE) {
+    if (t >= a.n) return;
+    k = a.scalars + 8 * t;
+  } else {
+    if (t >= a.L * a.n) return;
+    row = t / a.n; col = t - row * a.n;
+    k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+  }
   uint32_t carry = 0;
   for (int w = 0; w < s.W; w++) {
-    int d = window_digit(k, w, s.c, carry);
-    if (d != 0) atomicAdd(&hist[(size_t)w * s.nb + (d < 0 ? -d : d) - 1], 1u);
+    const int d = window_digit(k, w, s.c, carry);
+    if (d == 0) continue;
+    const size_t prob = (MODE == MODE_SINGLE) ? (size_t)w : row;
+    const size_t bkt = prob * s.nb + (size_t)((d < 0 ? -d : d) - 1);
+    if (!SCATTER) { atomicAdd(&hist_or_cursor[bkt], 1u); }
+    else {
+      const uint32_t pos = atomicAdd(&hist_or_cursor[bkt], 1u);
+      const uint32_t ent = (MODE == MODE_SINGLE) ? (uint32_t)t : (uint32_t)((size_t)w * a.tstride + col);
+      sorted[prob * a.estride + pos] = ent | (d < 0 ? 0x80000000u : 0u);
+    }
   }
 }
 
-// 2. exclusive scan per window: offs[w][b] = sum_{b'<b} hist[w][b'];  cursor = copy of offs.  One block per window.
+// exclusive scan per problem: offs[p][b] = sum_{b'<b} hist[p][b'];  cursor = copy of offs.  One block per problem.
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, int nb) {
   __shared__ uint32_t part[1024];
-  const int w = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+  const size_t w = blockIdx.x; const int t = threadIdx.x, T = blockDim.x;
   const int per = (nb + T - 1) / T;
-  const uint32_t* h = hist + (size_t)w * nb;
+  const uint32_t* h = hist + w * nb;
   uint32_t sum = 0;
   for (int j = 0; j < per; j++) { int b = t * per + j; if (b < nb) sum += h[b]; }
   part[t] = sum;
@@ -87,41 +119,58 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
   uint32_t run = part[t] - sum;
   for (int j = 0; j < per; j++) {
     int b = t * per + j;
-    if (b < nb) { offs[(size_t)w * nb + b] = run; cursor[(size_t)w * nb + b] = run; run += h[b]; }
+    if (b < nb) { offs[w * nb + b] = run; cursor[w * nb + b] = run; run += h[b]; }
   }
 }
 
-// 3. counting-sort scatter
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, size_t n, MsmShape s, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t* k = scalars + 8 * i;
-  uint32_t carry = 0;
-  for (int w = 0; w < s.W; w++) {
-    int d = window_digit(k, w, s.c, carry);
-    if (d != 0) {
-      uint32_t pos = atomicAdd(&cursor[(size_t)w * s.nb + (d < 0 ? -d : d) - 1], 1u);
-      sorted[(size_t)w * n + pos] = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
-    }
-  }
-}
+// ---- bucket accumulation -------------------------------------------------------------------------
+// A bucket's sorted entry list is cut into segments of SEG entries.  The owner lane takes segment 0; a bucket with
+// more (skewed scalars, or the short top window of a single MSM whose few buckets hold n/2^tb points each) posts its
+// other segments to a work list that k_acc_extra spreads over the whole chip, and k_acc_merge folds the partials
+// with one wave per oversized bucket.  No lane ever runs a chain longer than SEG mixed adds (+ a short merge).
+struct AccCounters { uint32_t extra_count, big_count; };
+struct ExtraItem { uint32_t bucket, seg; };
+struct BigItem { uint32_t bucket, base, k; };
 
-// 4. bucket accumulation: lane per (window, bucket)
-__global__ void __launch_bounds__(256) k_bucket_acc(const uint32_t* __restrict__ bases /* n x 16 u32, Montgomery affine */, size_t n, MsmShape s,
-                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
-                                                    const uint32_t* __restrict__ sorted, uint32_t* __restrict__ buckets /* W*nb x 32 u32 */) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)s.W * s.nb) return;
-  const int w = (int)(t / s.nb);
-  const uint32_t cnt = hist[t], start = offs[t];
-  const uint32_t* lst = sorted + (size_t)w * n + start;
+__device__ __forceinline__ XYZZ acc_segment(const uint32_t* __restrict__ points, const uint32_t* __restrict__ lst, uint32_t from, uint32_t to) {
   XYZZ acc = xyzz_inf();
-  for (uint32_t j = 0; j < cnt; j++) {
+  for (uint32_t j = from; j < to; j++) {
     const uint32_t e = lst[j];
-    const Affine p = aff_load(bases + 16 * (size_t)(e & 0x7fffffffu));
+    const Affine p = aff_load(points + 16 * (size_t)(e & 0x7fffffffu));
     xyzz_madd(acc, p, (e >> 31) != 0);
   }
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_acc_first(const uint32_t* __restrict__ points, size_t nbuckets, int nb, size_t estride, uint32_t SEG,
+                                                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                                   uint32_t* __restrict__ buckets, AccCounters* __restrict__ ctr, ExtraItem* __restrict__ extra, BigItem* __restrict__ big) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const uint32_t cnt = hist[t];
+  const uint32_t* lst = sorted + (t / nb) * estride + offs[t];
+  const XYZZ acc = acc_segment(points, lst, 0, cnt < SEG ? cnt : SEG);
   xyzz_store(buckets + 32 * t, acc);
+  if (cnt > SEG) {
+    const uint32_t k = (cnt + SEG - 1) / SEG - 1;
+    const uint32_t base = atomicAdd(&ctr->extra_count, k);
+    for (uint32_t j = 0; j < k; j++) { ExtraItem it; it.bucket = (uint32_t)t; it.seg = j + 1; extra[base + j] = it; }
+    BigItem bi; bi.bucket = (uint32_t)t; bi.base = base; bi.k = k;
+    big[atomicAdd(&ctr->big_count, 1u)] = bi;
+  }
+}
+__global__ void __launch_bounds__(256) k_acc_extra(const uint32_t* __restrict__ points, int nb, size_t estride, uint32_t SEG,
+                                                   const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                                   const AccCounters* __restrict__ ctr, const ExtraItem* __restrict__ extra, uint32_t* __restrict__ extra_out) {
+  const uint32_t total = ctr->extra_count;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const ExtraItem it = extra[i];
+    const size_t t = it.bucket;
+    const uint32_t cnt = hist[t];
+    const uint32_t* lst = sorted + (t / nb) * estride + offs[t];
+    const uint32_t from = it.seg * SEG, to = (from + SEG < cnt) ? from + SEG : cnt;
+    xyzz_store(extra_out + 32 * i, acc_segment(points, lst, from, to));
+  }
 }
 
 // ---- weighted bucket sums --------------------------------------------------------------------
@@ -146,6 +195,19 @@ __device__ __forceinline__ XYZZ xyzz_mul_pow2(XYZZ v, int k) {
 #pragma unroll 1
   for (int i = 0; i < k; i++) v = xyzz_dbl(v);
   return v;
+}
+
+// one wave per oversized bucket: bucket += sum of its k extra partials (lane-strided chains, then a wave tree)
+__global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets) {
+  const int lane = threadIdx.x;
+  const uint32_t total = ctr->big_count;
+  for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
+    const BigItem bi = big[i];
+    XYZZ acc = (lane == 0) ? xyzz_load(buckets + 32 * (size_t)bi.bucket) : xyzz_inf();
+    for (uint32_t j = lane; j < bi.k; j += 64) acc = xyzz_add(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
+    acc = wave_sum(acc, lane);
+    if (lane == 0) xyzz_store(buckets + 32 * (size_t)bi.bucket, acc);
+  }
 }
 
 // level 1: one wave per chunk of 64*L consecutive buckets of one problem (window).
@@ -202,6 +264,18 @@ __global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restric
   }
 }
 
+// window table for MODE_ROWS: slab w holds 2^(c*w) * P_j for every base j (XYZZ here; k_xyzz_to_affine finishes it).
+// Setup only, once per generator set and window size.
+__global__ void __launch_bounds__(64) k_window_table(const uint32_t* __restrict__ bases /* npts Montgomery affine */, size_t npts, int c, int W, uint32_t* __restrict__ out_xyzz) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npts) return;
+  XYZZ p = xyzz_from_affine(aff_load(bases + 16 * j));
+  for (int w = 0; w < W; w++) {
+    xyzz_store(out_xyzz + 32 * ((size_t)w * npts + j), p);
+    if (w + 1 < W) p = xyzz_mul_pow2(p, c);
+  }
+}
+
 // XYZZ -> affine for `count` points, one lane each (Fermat inversion): Montgomery coordinates for resident tables
 // and/or canonical little-endian bytes for the caller; either output may be null.
 __global__ void __launch_bounds__(64) k_xyzz_to_affine(const uint32_t* __restrict__ in, uint32_t* __restrict__ out_mont, uint32_t* __restrict__ out_xy, uint8_t* __restrict__ out_inf, size_t count) {
@@ -229,6 +303,26 @@ __global__ void __launch_bounds__(64) k_mul_generator(const uint32_t* __restrict
     if ((k[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, G, false);
   }
   xyzz_store(out_xyzz + 32 * i, acc);
+}
+
+// P_i = P0 + (first + i) * D : lane-local double-and-add on the 64-bit index (synthetic bases with known dlogs)
+__global__ void __launch_bounds__(64) k_arith_points(const uint32_t* __restrict__ p0d /* P0, D as XYZZ */, unsigned long long first, size_t n, uint32_t* __restrict__ out_xyzz) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const XYZZ P0 = xyzz_load(p0d), D = xyzz_load(p0d + 32);
+  unsigned long long k = first + i;
+  XYZZ acc = xyzz_inf();
+  for (int b = 63; b >= 0; b--) {
+    if (!xyzz_is_inf(acc)) acc = xyzz_dbl(acc);
+    if ((k >> b) & 1ull) acc = xyzz_add(acc, D);
+  }
+  xyzz_store(out_xyzz + 32 * i, xyzz_add(acc, P0));
+}
+__global__ void __launch_bounds__(256) k_points_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store<FqP>(out + 16 * i, fe_from_mont(fe_load<FqP>(in + 16 * i)));
+  fe_store<FqP>(out + 16 * i + 8, fe_from_mont(fe_load<FqP>(in + 16 * i + 8)));
 }
 
 }  // namespace sbn

@@ -40,7 +40,7 @@ struct sbn_ctx {
   std::string err;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
-  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list;
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
   // profiling
   bool prof = false;
@@ -53,6 +53,7 @@ struct sbn_bases {
   size_t n = 0;           // number of G points
   bool has_h = false;
   void* d_pts = nullptr;  // (n + has_h) x 64 B, Montgomery affine
+  mutable std::unordered_map<int, void*> tables;   // window bits c -> W x (n + has_h) x 64 B: 2^(c w) * P_j (built on first commit)
 };
 
 struct sbn_table {
@@ -115,75 +116,160 @@ struct ProfScope {
 // ------------------------------------------------------------------------------------------------
 static int ilog2_ceil(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return l; }
 
-// Window size for a single MSM of n terms.  Cost model: n*W mixed adds (10 products) + 2*W*2^(c-1) full adds
-// (14 products); tuned on MI355X.  SBN_MSM_C overrides for experiments.
-static MsmShape choose_shape(size_t n) {
-  int c;
-  const char* env = getenv("SBN_MSM_C");
-  if (env && atoi(env) >= 7 && atoi(env) <= 22) c = atoi(env);
-  else {
-    int lg = ilog2_ceil(n < 2 ? 2 : n);
-    c = lg - 4;
-    if (c < 7) c = 7;
-    if (c > 20) c = 20;
-  }
+// Signed radix-2^c digits: W windows cover 254 bits, the top digit (+ carry) must stay <= 2^(c-1).
+static MsmShape make_shape(int c) {
   MsmShape s; s.c = c; s.nb = 1 << (c - 1);
   int W = (254 + c - 1) / c;
   int tb = 254 - (W - 1) * c;          // bits in the top window
-  if (tb > c - 1) W += 1;              // top digit + carry must stay <= 2^(c-1)
+  if (tb > c - 1) W += 1;
   s.W = W;
   return s;
 }
+// Window size from a cost model in modular products: `terms`*W mixed adds (10 each) into `sets` bucket sets of 2^(c-1)
+// buckets, each bucket costing ~2 full adds (14 each) in the running-sum reduction (x2 for the wave-level part).
+// SBN_MSM_C overrides for experiments.
+static MsmShape choose_shape(size_t terms, bool shared_bucket_set) {
+  const char* env = getenv("SBN_MSM_C");
+  if (env && atoi(env) >= 7 && atoi(env) <= 22) return make_shape(atoi(env));
+  double best = 1e300; int bc = 7;
+  for (int c = 7; c <= 20; c++) {
+    MsmShape s = make_shape(c);
+    double sets = shared_bucket_set ? 1.0 : (double)s.W;
+    double cost = (double)terms * s.W * 10.0 + sets * s.nb * 56.0;
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return make_shape(bc);
+}
 
-// MSM over device-resident canonical scalars and Montgomery affine bases; result -> XYZZ on host, then affine bytes
-static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_bases, size_t n, uint8_t out_xy[64], int* out_is_inf) {
-  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
-  if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
-  const MsmShape s = choose_shape(n);
-  const size_t NB = (size_t)s.W * s.nb;
+struct BucketJob {
+  int mode; DigitArgs da; MsmShape s;
+  size_t P;               // problems (windows or rows)
+  size_t threads;         // digit-kernel threads
+  const uint32_t* points; // Montgomery affine points the entries index
+};
+
+// digits -> counting sort -> segmented bucket accumulation -> per-problem weighted sums in c->wsum (P x XYZZ)
+static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
+  const MsmShape& s = J.s;
+  const size_t NB = J.P * (size_t)s.nb;
+  if (NB > 0xffffffffull) return fail(c, SBN_EINVAL, "bucket space too large");
+  const size_t estride = J.da.estride;
+  // segment length: twice the mean bucket load (power of two, >= 32)
+  size_t mean = estride / (size_t)s.nb + 1;
+  uint32_t SEG = 32; while (SEG < 2 * mean) SEG <<= 1;
+  const size_t max_extra = J.P * estride / SEG + 1;
+  const size_t max_big = std::min(NB, max_extra);
   int rc;
   if ((rc = ensure(c, c->hist, NB * 4))) return rc;
   if ((rc = ensure(c, c->offs, NB * 4))) return rc;
   if ((rc = ensure(c, c->cursor, NB * 4))) return rc;
-  if ((rc = ensure(c, c->sorted, (size_t)s.W * n * 4))) return rc;
+  if ((rc = ensure(c, c->sorted, J.P * estride * 4))) return rc;
   if ((rc = ensure(c, c->buckets, NB * 128))) return rc;
-  // reduction geometry: chunk = 64*L buckets per wave
+  if ((rc = ensure(c, c->acc_ctr, 64))) return rc;
+  if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
+  if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
+  if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
   int L = s.nb / 64; if (L > 8) L = 8; if (L < 1) L = 1;
   int logL = 0; while ((1 << logL) < L) logL++;
-  const int chunks = s.nb / (64 * L);                     // per window, >= 1
-  if ((rc = ensure(c, c->red_a, (size_t)s.W * chunks * 256))) return rc;
-  if ((rc = ensure(c, c->red_b, (size_t)s.W * ((chunks + 63) / 64) * 256))) return rc;
-  if ((rc = ensure(c, c->wsum, (size_t)s.W * 128))) return rc;
-  if ((rc = ensure_pin(c, (size_t)s.W * 128))) return rc;
+  const int chunks = s.nb / (64 * L);                     // per problem, >= 1
+  if ((rc = ensure(c, c->red_a, J.P * chunks * 256))) return rc;
+  if ((rc = ensure(c, c->red_b, J.P * ((chunks + 63) / 64) * 256))) return rc;
+  if ((rc = ensure(c, c->wsum, J.P * 128))) return rc;
 
   uint32_t* hist = (uint32_t*)c->hist.p; uint32_t* offs = (uint32_t*)c->offs.p; uint32_t* cursor = (uint32_t*)c->cursor.p;
   uint32_t* sorted = (uint32_t*)c->sorted.p; uint32_t* buckets = (uint32_t*)c->buckets.p;
+  AccCounters* ctr = (AccCounters*)c->acc_ctr.p;
 
   HIPCHK(c, hipMemsetAsync(hist, 0, NB * 4, c->stream));
-  const unsigned gn = (unsigned)((n + 255) / 256);
-  LAUNCH(c, "k_digits_hist", k_digits_hist, gn, 256, d_scal, n, s, hist);
-  LAUNCH(c, "k_scan", k_scan, s.W, 1024, hist, offs, cursor, s.nb);
-  LAUNCH(c, "k_scatter", k_scatter, gn, 256, d_scal, n, s, cursor, sorted);
-  LAUNCH(c, "k_bucket_acc", k_bucket_acc, (unsigned)((NB + 255) / 256), 256, d_bases, n, s, hist, offs, sorted, buckets);
-  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(s.W * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
-  // combine levels until one result per window
+  HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(AccCounters), c->stream));
+  const unsigned gd = (unsigned)((J.threads + 255) / 256);
+  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_hist", (k_digits<MODE_SINGLE, false>), gd, 256, J.da, s, hist, sorted);
+  else LAUNCH(c, "k_digits_hist", (k_digits<MODE_ROWS, false>), gd, 256, J.da, s, hist, sorted);
+  LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, cursor, s.nb);
+  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_scatter", (k_digits<MODE_SINGLE, true>), gd, 256, J.da, s, cursor, sorted);
+  else LAUNCH(c, "k_digits_scatter", (k_digits<MODE_ROWS, true>), gd, 256, J.da, s, cursor, sorted);
+  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, buckets, ctr,
+         (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
+  LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
+  LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
   int G = chunks, logM = 6 + logL;
   for (;;) {
     int Gout = (G + 63) / 64;
     int final = (Gout == 1);
-    LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(s.W * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
     if (final) break;
     std::swap(in, outb); G = Gout; logM += 6;
   }
   LAUNCHCHK(c);
-  HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, (size_t)s.W * 128, hipMemcpyDeviceToHost, c->stream));
+  return SBN_OK;
+}
+
+// MSM over device-resident canonical scalars and Montgomery affine bases -> canonical affine bytes on the host
+static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_bases, size_t n, uint8_t out_xy[64], int* out_is_inf) {
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
+  BucketJob J; memset(&J, 0, sizeof J);
+  J.mode = MODE_SINGLE; J.s = choose_shape(n, false); J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
+  J.da.scalars = d_scal; J.da.n = n; J.da.estride = n;
+  int rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;
+  if ((rc = run_bucket_job(c, J))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, J.P * 128, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof) prof_drain(c);
-  // 254-doubling serial chain on the host
+  // sum_w 2^(c w) S_w: the 254-doubling serial chain, on the host
   const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
-  sbn_host::Pt total = sbn_host::combine_windows(S, s.W, s.c);
+  sbn_host::Pt total = sbn_host::combine_windows(S, J.s.W, J.s.c);
   sbn_host::to_affine_bytes(total, out_xy, out_is_inf);
+  return SBN_OK;
+}
+
+// window table 2^(c w) * P_j of a generator set, built on first use for a given c and kept with the handle
+static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s, const uint32_t** out) {
+  auto it = b->tables.find(s.c);
+  if (it != b->tables.end()) { *out = (const uint32_t*)it->second; return SBN_OK; }
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  const size_t tot = npts * (size_t)s.W;
+  int rc;
+  if ((rc = ensure(c, c->gen_tmp, tot * 128))) return rc;
+  void* tab = nullptr;
+  hipError_t e = hipMalloc(&tab, tot * 64);
+  if (e != hipSuccess) return fail(c, SBN_ENOMEM, "hipMalloc window table (%zu B): %s", tot * 64, hipGetErrorString(e));
+  LAUNCH(c, "k_window_table", k_window_table, (unsigned)((npts + 63) / 64), 64, (const uint32_t*)b->d_pts, npts, s.c, s.W, (uint32_t*)c->gen_tmp.p);
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((tot + 63) / 64), 64, (const uint32_t*)c->gen_tmp.p, (uint32_t*)tab, (uint32_t*)nullptr, (uint8_t*)nullptr, tot);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->tables[s.c] = tab;
+  *out = (const uint32_t*)tab;
+  return SBN_OK;
+}
+
+// Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
+static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+  if (L == 0) return SBN_OK;
+  const size_t ncol = R + (dBl ? 1 : 0);
+  if (ncol == 0) { memset(out_xy, 0, 64 * L); if (out_inf) memset(out_inf, 1, L); return SBN_OK; }
+  BucketJob J; memset(&J, 0, sizeof J);
+  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true); J.P = L; J.threads = L * ncol;
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  if ((size_t)J.s.W * npts > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: table index overflow");
+  int rc; const uint32_t* tab;
+  if ((rc = bases_window_table(c, b, J.s, &tab))) return rc;
+  J.points = tab;
+  J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
+  if ((rc = run_bucket_job(c, J))) return rc;
+  if ((rc = ensure(c, c->out_small, L * 65))) return rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
+  uint32_t* d_xy = (uint32_t*)c->out_small.p; uint8_t* d_inf = (uint8_t*)c->out_small.p + L * 64;
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->out_small.p, L * 65, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  memcpy(out_xy, c->pin, L * 64);
+  if (out_inf) memcpy(out_inf, (uint8_t*)c->pin + L * 64, L);
   return SBN_OK;
 }
 
@@ -232,7 +318,7 @@ void sbn_ctx_destroy(sbn_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_drain(c);
   DevBuf* bufs[] = {&c->scal_canon, &c->pts_mont, &c->hist, &c->offs, &c->cursor, &c->sorted, &c->buckets, &c->red_a, &c->red_b, &c->wsum, &c->stage_scal, &c->stage_pts, &c->out_small,
-                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp};
+                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (c->pin) hipHostFree(c->pin);
   for (hipEvent_t e : c->evt_pool) hipEventDestroy(e);
@@ -265,7 +351,7 @@ int sbn_bases_upload(sbn_ctx* c, const uint8_t* G_xy, size_t n, const uint8_t* h
   *out = b;
   return SBN_OK;
 }
-void sbn_bases_free(sbn_ctx* c, sbn_bases* b) { if (!b) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (b->d_pts) hipFree(b->d_pts); delete b; }
+void sbn_bases_free(sbn_ctx* c, sbn_bases* b) { if (!b) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (b->d_pts) hipFree(b->d_pts); for (auto& kv : b->tables) hipFree(kv.second); delete b; }
 size_t sbn_bases_len(const sbn_bases* b) { return b ? b->n : 0; }
 
 int sbn_msm_bases_dev(sbn_ctx* c, const sbn_bases* b, const void* d_scalars, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
@@ -301,28 +387,22 @@ int sbn_msm(sbn_ctx* c, const uint8_t* scalars, const uint8_t* points, size_t n,
   return msm_device(c, ds, (const uint32_t*)c->stage_pts.p, n, out_xy, out_is_inf);
 }
 
-// v1: one MSM per row (correct for every shape; the batched shared-base kernels replace this loop)
 int sbn_commit_rows_dev(sbn_ctx* c, const sbn_bases* b, const void* Z_dev, const void* blinds_dev, size_t L, size_t R, uint32_t flags, uint8_t* out_xy, uint8_t* out_inf) {
-  if (!c || !b || !out_xy || (!Z_dev && L * R)) return SBN_EINVAL;
+  if (!c || !b || (!out_xy && L) || (!Z_dev && L * R)) return SBN_EINVAL;
   if (R != b->n) return fail(c, SBN_EINVAL, "commit: gens_n.n (%zu) != row length (%zu)  [commitments.rs:146 assert_eq]", b->n, R);
   if (blinds_dev && !b->has_h) return fail(c, SBN_EINVAL, "commit: blinds given but the table has no h");
   std::lock_guard<std::mutex> g(c->mu);
   hipSetDevice(c->device);
-  int rc;
-  const size_t n1 = R + (blinds_dev ? 1 : 0);
-  if ((rc = ensure(c, c->out_small, n1 * 32))) return rc;
-  for (size_t i = 0; i < L; i++) {
-    // row scalars || blind, contiguous, canonical
-    uint8_t* row = (uint8_t*)c->out_small.p;
-    HIPCHK(c, hipMemcpyAsync(row, (const uint8_t*)Z_dev + i * R * 32, R * 32, hipMemcpyDeviceToDevice, c->stream));
-    if (blinds_dev) HIPCHK(c, hipMemcpyAsync(row + R * 32, (const uint8_t*)blinds_dev + i * 32, 32, hipMemcpyDeviceToDevice, c->stream));
-    const uint32_t* ds;
-    if ((rc = canon_scalars_dev(c, row, n1, flags, &ds))) return rc;
-    int inf = 0;
-    if ((rc = msm_device(c, ds, (const uint32_t*)b->d_pts, n1, out_xy + 64 * i, &inf))) return rc;
-    if (out_inf) out_inf[i] = (uint8_t)inf;
+  const uint32_t* dZ = (const uint32_t*)Z_dev; const uint32_t* dB = (const uint32_t*)blinds_dev;
+  if (flags & SBN_SCALARS_MONT) {
+    int rc;
+    if ((rc = ensure(c, c->scal_canon, (L * R + L) * 32))) return rc;
+    uint32_t* o = (uint32_t*)c->scal_canon.p;
+    if (L * R) LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((L * R + 255) / 256), 256, dZ, o, L * R);
+    dZ = o;
+    if (dB) { LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((L + 255) / 256), 256, dB, o + 8 * L * R, L); dB = o + 8 * L * R; }
   }
-  return SBN_OK;
+  return commit_rows_device(c, b, dZ, dB, L, R, out_xy, out_inf);
 }
 int sbn_commit_rows(sbn_ctx* c, const sbn_bases* b, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R, uint32_t flags, uint8_t* out_xy, uint8_t* out_inf) {
   if (!c || !b || !out_xy || (!Z && L * R)) return SBN_EINVAL;
@@ -352,6 +432,21 @@ int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32) {
     if (!gt) { gt = false; for (int k = 3; k >= 0; k--) { if (t[k] > sbn_host::QP[k]) { gt = true; break; } if (t[k] < sbn_host::QP[k]) break; } }
     if (gt) o[31] |= 0x80;
   }
+  return SBN_OK;
+}
+int sbn_g1_sum(const uint8_t* xy, size_t n, uint8_t out_xy[64], int* out_is_inf) {
+  if (!out_xy || (!xy && n)) return SBN_EINVAL;
+  sbn_host::Pt acc = sbn_host::inf();
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* p = xy + 64 * i;
+    bool inf = true; for (int k = 0; k < 64; k++) if (p[k]) { inf = false; break; }
+    if (inf) continue;
+    sbn_host::Fq x, y; memcpy(x.v, p, 32); memcpy(y.v, p + 32, 32);
+    if (sbn_host::geq_p(x.v) || sbn_host::geq_p(y.v)) return SBN_EINVAL;   // not canonical
+    sbn_host::Pt q; q.X = sbn_host::to_mont(x); q.Y = sbn_host::to_mont(y); q.ZZ = sbn_host::one(); q.ZZZ = sbn_host::one();
+    acc = sbn_host::padd(acc, q);
+  }
+  sbn_host::to_affine_bytes(acc, out_xy, out_is_inf);
   return SBN_OK;
 }
 void sbn_factored_lens(size_t ell, size_t* left, size_t* right) { if (left) *left = ell / 2; if (right) *right = ell - ell / 2; }
@@ -398,6 +493,42 @@ int sbn_gens_new(sbn_ctx* c, size_t n, const uint8_t* label, size_t label_len, u
   if (out_xy) HIPCHK(c, hipMemcpyAsync(out_xy, d_xy, tot * 64, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = b;
+  return SBN_OK;
+}
+
+int sbn_bases_synthetic(sbn_ctx* c, size_t n, uint64_t first, const uint8_t s0[32], const uint8_t d[32], sbn_bases** out) {
+  if (!c || !out || !s0 || !d || n == 0) return SBN_EINVAL;
+  if (!fr_canonical(s0) || !fr_canonical(d)) return fail(c, SBN_EINVAL, "synthetic bases: s0/d not canonical");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  int rc;
+  if ((rc = ensure(c, c->gen_tmp, 64 + 256 + n * 128))) return rc;
+  uint8_t* d_s = (uint8_t*)c->gen_tmp.p; uint8_t* d_p0d = d_s + 64; uint8_t* d_x = d_p0d + 256;
+  HIPCHK(c, hipMemcpyAsync(d_s, s0, 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_s + 32, d, 32, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_mul_generator", k_mul_generator, 1, 64, (const uint32_t*)d_s, (size_t)2, (uint32_t*)d_p0d);
+  LAUNCH(c, "k_arith_points", k_arith_points, (unsigned)((n + 63) / 64), 64, (const uint32_t*)d_p0d, (unsigned long long)first, n, (uint32_t*)d_x);
+  sbn_bases* b = new sbn_bases(); b->n = n; b->has_h = false;
+  hipError_t e = hipMalloc(&b->d_pts, n * 64);
+  if (e != hipSuccess) { delete b; return fail(c, SBN_ENOMEM, "hipMalloc synthetic bases: %s", hipGetErrorString(e)); }
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((n + 63) / 64), 64, (const uint32_t*)d_x, (uint32_t*)b->d_pts, (uint32_t*)nullptr, (uint8_t*)nullptr, n);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *out = b;
+  return SBN_OK;
+}
+int sbn_bases_download(sbn_ctx* c, const sbn_bases* b, size_t first, size_t count, uint8_t* out_xy) {
+  if (!c || !b || (!out_xy && count)) return SBN_EINVAL;
+  const size_t tot = b->n + (b->has_h ? 1 : 0);
+  if (first > tot || count > tot - first) return fail(c, SBN_EINVAL, "bases_download: range outside the table");
+  if (count == 0) return SBN_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  int rc; if ((rc = ensure(c, c->stage_pts, count * 64))) return rc;
+  LAUNCH(c, "k_points_from_mont", k_points_from_mont, (unsigned)((count + 255) / 256), 256, (const uint32_t*)b->d_pts + 16 * first, (uint32_t*)c->stage_pts.p, count);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(out_xy, c->stage_pts.p, count * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return SBN_OK;
 }
 

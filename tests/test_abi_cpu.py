@@ -1,0 +1,97 @@
+"""CPU: the C-ABI library loads, exports every symbol include/sbn254.h declares, its host-only helpers agree with the
+oracle, and the device entry points fail loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import pytest
+from conftest import ROOT, golden
+
+H = bytes.fromhex
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "sbn254.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sbn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(sbn):
+    import ctypes
+    lib = ctypes.CDLL(sbn.lib_path())
+    names = header_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sbn254.h but not exported"
+    assert sorted(sbn.EXPORTED_SYMBOLS) == names, "binding.py symbol list and the header disagree"
+
+
+def test_no_oracle_in_product():
+    """the product path must not include, link or call oracle/ (③)"""
+    pk = os.path.join(ROOT, "spartan-bn254_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "bn254_oracle" not in txt and "libsbn_oracle" not in txt and "orc_" not in txt, f
+                assert "oracle_lib" not in txt, f
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pk, "libsbn254_hip.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+
+
+def test_version_and_lens(sbn):
+    assert b"gfx950" in sbn.lib().sbn_version()
+    # hyrax.rs:371-373 ; derefs at keyless size: ell = 25 -> 4096 x 8192
+    assert sbn.factored_lens(25) == (12, 13)
+    assert sbn.factored_lens(20) == (10, 10)
+    assert sbn.factored_lens(1) == (0, 1)
+    assert sbn.factored_lens(0) == (0, 0)
+
+
+def test_compress_matches_oracle_and_golden(sbn, ol, pr):
+    g = golden("g1_kat.json")
+    pts = b"".join(H(r["kG"]) for r in g["mul"]) + bytes(64)
+    want = b"".join(H(r["compressed"]) for r in g["mul"]) + bytes(31) + b"\x40"
+    assert sbn.g1_compress(pts) == want
+    assert sbn.g1_compress(pts) == b"".join(ol.g1_compress(pts[64 * i:64 * i + 64]) for i in range(len(pts) // 64))
+    assert sbn.g1_compress(b"") == b""
+
+
+def test_g1_sum_host(sbn, ol, pr):
+    G = pr.point_to_xy(pr.G)
+    out, inf = sbn.g1_sum(G + G + G)
+    assert out == ol.g1_mul(G, (3).to_bytes(32, "little")) and not inf
+    out, inf = sbn.g1_sum(G + ol.g1_neg(G))
+    assert inf and out == bytes(64)
+    out, inf = sbn.g1_sum(b"")
+    assert inf
+    out, inf = sbn.g1_sum(bytes(64) + G + bytes(64))
+    assert out == G
+    for row in golden("g1_kat.json")["add"]:
+        out, _ = sbn.g1_sum(H(row["p"]) + H(row["q"]))
+        assert out == H(row["sum"]), row["note"]
+    with pytest.raises(sbn.SbnError):
+        sbn.g1_sum(b"\xff" * 64)          # non-canonical coordinates are rejected
+
+
+def test_device_entry_points_fail_loudly_without_gpu(sbn):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(sbn.SbnError):
+        sbn.Context(0)
+
+
+def test_shard_ranges(sbn):
+    from spartan_bn254_amd import sharding
+    for n in (0, 1, 7, 8, 1000, (1 << 20) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    rows = sorted(sum((sharding.shard_rows(4096, r, 8) for r in range(8)), []))
+    assert rows == list(range(4096))
+    # zero-padding rows 3072.. (hyrax.rs:245) spread evenly over the ranks
+    assert all(sum(1 for x in sharding.shard_rows(4096, r, 8) if x >= 3072) == 128 for r in range(8))

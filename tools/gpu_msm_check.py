@@ -43,8 +43,28 @@ out, inf = ctx.msm(rm1 + (1).to_bytes(32, "little"), G + G); print("(r-1)G+G=inf
 nG = ol.g1_neg(G)
 out, inf = ctx.msm(k3 + k3, G + nG); print("3G-3G=inf:", inf); ok &= inf
 out, inf = ctx.msm(k3 * 40, G * 40); e = ol.g1_mul(G, (120).to_bytes(32, "little")); print("40 x 3G:", out == e); ok &= out == e
+# skewed scalars: every scalar equal -> one bucket per window holds all n points (segment splitting path)
+n = 5000
+kb1, pts, _ = synth(n, 11)
+same = kb1[:32] * n
+out, inf = ctx.msm(same, pts); e = ol.msm_pippenger(same, pts, 8); print("all-equal scalars n=5000:", out == e); ok &= out == e
+# Hyrax row commits (MODE_ROWS): L x R with and without blinds, zero rows, constant rows
+for (L, R) in [(1, 1), (3, 5), (8, 64), (16, 300), (4, 1025)]:
+    gx, gdl = ol.gens_new(R, b"gens_r1cs_eval")
+    Gxy, hxy = gx[: 64 * R], gx[64 * R:]
+    rng = np.random.default_rng(L * 1000 + R)
+    Z = bytearray(b"".join((int.from_bytes(rng.bytes(32), "little") % pr.R).to_bytes(32, "little") for _ in range(L * R)))
+    if L >= 3:
+        Z[32 * R: 64 * R] = bytes(32 * R)                         # an all-zero row -> identity
+        Z[64 * R: 96 * R] = Z[64 * R: 64 * R + 32] * R            # a constant row
+    Z = bytes(Z)
+    bl = b"".join((int.from_bytes(rng.bytes(32), "little") % pr.R).to_bytes(32, "little") for _ in range(L))
+    b = ctx.bases_upload(Gxy, hxy)
+    out, infs = ctx.commit_rows(b, Z, bl, L, R); e = ol.commit_rows(Z, bl, L, R, Gxy, hxy, 8); print(f"commit_rows {L}x{R} blinds:", out == e); ok &= out == e
+    out, infs = ctx.commit_rows(b, Z, None, L, R); e = ol.commit_rows(Z, None, L, R, Gxy, hxy, 8); print(f"commit_rows {L}x{R} no blinds:", out == e, list(infs)[:4]); ok &= out == e
+    b.free()
 # timing with resident bases
-for n in [1 << 16, 1 << 18, 1 << 20]:
+for n in [1 << 16, 1 << 18, 1 << 20, 1 << 22]:
     kb, pts, exp = synth(n, 7) if n <= (1 << 18) else (None, None, None)
     if kb is None:
         rng = np.random.default_rng(3); k = rng.integers(0, 2**32, size=(n, 8), dtype=np.uint32); k[:, 7] &= 0x0fffffff; kb = k.tobytes()
@@ -59,5 +79,18 @@ for n in [1 << 16, 1 << 18, 1 << 20]:
     print(f"resident n={n}: {dt*1e3:.3f} ms/msm  {n/dt:.3e} pts/s  match={out == exp if exp else 'n/a'}")
     for name, (ms, cnt) in ctx.prof_get().items(): print(f"    {name:24s} {ms/cnt:9.3f} ms avg x{cnt}")
     ctx.prof_enable(False); ctx.dev_free(dptr); b.free()
+# Hyrax shape timing: rows x 8192 over the reference generator set
+R = 8192
+t0 = time.time(); bg, gxy = ctx.gens_new(R, b"gens_r1cs_eval", want_points=False); print(f"gens_new(8192): {(time.time()-t0)*1e3:.1f} ms")
+for L in [64, 512]:
+    rng = np.random.default_rng(5); Zk = rng.integers(0, 2**32, size=(L * R, 8), dtype=np.uint32); Zk[:, 7] &= 0x0fffffff
+    dptr = ctx.dev_alloc(L * R * 32); ctx.dev_upload(dptr, Zk.tobytes())
+    ctx.prof_enable(True); ctx.prof_reset()
+    out, infs = ctx.commit_rows_dev(bg, dptr, 0, L, R)
+    ctx.prof_reset()
+    t0 = time.time(); out, infs = ctx.commit_rows_dev(bg, dptr, 0, L, R); dt = time.time() - t0
+    print(f"commit_rows {L}x{R}: {dt*1e3:.2f} ms  {L*R/dt:.3e} pairs/s")
+    for name, (ms, cnt) in ctx.prof_get().items(): print(f"    {name:24s} {ms/cnt:9.3f} ms avg x{cnt}")
+    ctx.prof_enable(False); ctx.dev_free(dptr)
 print("MSM CHECK", "OK" if ok else "FAIL")
 sys.exit(0 if ok else 1)
