@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_*/) into the tracked summaries under profiles/.
+
+  python tools/summarize_prof.py <prof_dir> <tag> <workload>
+
+Reads <prof_dir>/trace/**/_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and the two separate PMC passes
+<prof_dir>/pmc_fetch, <prof_dir>/pmc_write (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; they cannot share a pass: TCC has 4
+slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 — MI355X_MICROARCH.md).  Units and corrections as that guide prescribes:
+counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes actually fetched, so the read side is doubled.
+Writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.csv and updates profiles/pmc_traffic.json (bytes/launch).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("sbn::", "")
+    if n.startswith("k_digits<"):
+        n = "k_digits_scatter" if "true" in n else "k_digits_hist"
+    return n
+
+
+def main():
+    prof_dir, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    stats = glob.glob(os.path.join(prof_dir, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs']) / 1e6:.4f}", f"{float(r['AverageNs']) / 1e6:.4f}", r["Percentage"],
+                            f"{float(r['MinNs']) / 1e6:.4f}", f"{float(r['MaxNs']) / 1e6:.4f}"])
+        print("wrote", f"profiles/{tag}_kernel_stats.csv")
+    sums = defaultdict(lambda: defaultdict(float)); cnts = defaultdict(lambda: defaultdict(int))
+    for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for path in glob.glob(os.path.join(prof_dir, sub, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == ctr:
+                    k = short(r["Kernel_Name"])
+                    sums[k][ctr] += float(r["Counter_Value"]); cnts[k][ctr] += 1
+    traffic = {}
+    with open(os.path.join(out_dir, f"{tag}_pmc.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "FETCH_SIZE_KiB_per_launch_raw", "WRITE_SIZE_KiB_per_launch", "hbm_bytes_per_launch (2*FETCH + WRITE) * 1024"])
+        for k in sorted(sums):
+            fe = sums[k]["FETCH_SIZE"] / max(cnts[k]["FETCH_SIZE"], 1)
+            wr = sums[k]["WRITE_SIZE"] / max(cnts[k]["WRITE_SIZE"], 1)
+            b = (2.0 * fe + wr) * 1024.0
+            traffic[k] = round(b)
+            w.writerow([k, cnts[k]["FETCH_SIZE"], f"{fe:.2f}", f"{wr:.2f}", f"{b:.0f}"])
+    print("wrote", f"profiles/{tag}_pmc.csv")
+    tj = os.path.join(out_dir, "pmc_traffic.json")
+    allt = json.load(open(tj)) if os.path.exists(tj) else {}
+    allt[workload] = traffic
+    allt.setdefault("_source", {})[workload] = f"{tag}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `python3 bench.py --workload {workload}`; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch"
+    json.dump(allt, open(tj, "w"), indent=1, sort_keys=True)
+    print("updated profiles/pmc_traffic.json")
+
+
+if __name__ == "__main__":
+    main()
