@@ -27,7 +27,7 @@ struct MsmShape {
   int nb;       // buckets per window = 2^(c-1)
 };
 
-// signed digit of window w; carry in/out.  digit in (-2^(c-1), 2^(c-1)]
+// signed digit of window w; carry in/out.  digit in [-2^(c-1), 2^(c-1)) (ark-ec's recentring)
 __device__ __forceinline__ int window_digit(const uint32_t* __restrict__ k /* 8 limbs, global */, int w, int c, uint32_t& carry) {
   const int bit = w * c, limb = bit >> 5, sh = bit & 31;
   uint64_t x = 0;
@@ -35,7 +35,7 @@ __device__ __forceinline__ int window_digit(const uint32_t* __restrict__ k /* 8 
   if (limb + 1 < 8) x |= (uint64_t)k[limb + 1] << 32;
   const uint32_t raw = (uint32_t)(x >> sh) & ((1u << c) - 1u);
   const uint32_t d = raw + carry;
-  if (d > (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
+  if (d >= (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
   carry = 0;
   return (int)d;
 }
@@ -73,8 +73,10 @@ struct DigitArgs {
   size_t estride;            // sorted-entry capacity per problem
 };
 
-template <int MODE, bool SCATTER>
-__global__ void __launch_bounds__(256) k_digits(DigitArgs a, MsmShape s, uint32_t* __restrict__ hist_or_cursor, uint32_t* __restrict__ sorted) {
+// signed digits of every scalar, stored once (int32): dig[p*E + e]
+//   SINGLE: p = window w, e = scalar index          ROWS: p = row, e = w*ncol + col
+template <int MODE>
+__global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, int32_t* __restrict__ dig) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* k; size_t row = 0, col = 0;
   if (MODE == MODE_SINGLE) {
@@ -88,15 +90,72 @@ __global__ void __launch_bounds__(256) k_digits(DigitArgs a, MsmShape s, uint32_
   uint32_t carry = 0;
   for (int w = 0; w < s.W; w++) {
     const int d = window_digit(k, w, s.c, carry);
-    if (d == 0) continue;
-    const size_t prob = (MODE == MODE_SINGLE) ? (size_t)w : row;
-    const size_t bkt = prob * s.nb + (size_t)((d < 0 ? -d : d) - 1);
-    if (!SCATTER) { atomicAdd(&hist_or_cursor[bkt], 1u); }
-    else {
-      const uint32_t pos = atomicAdd(&hist_or_cursor[bkt], 1u);
-      const uint32_t ent = (MODE == MODE_SINGLE) ? (uint32_t)t : (uint32_t)((size_t)w * a.tstride + col);
-      sorted[prob * a.estride + pos] = ent | (d < 0 ? 0x80000000u : 0u);
-    }
+    if (MODE == MODE_SINGLE) dig[(size_t)w * a.n + t] = d;
+    else dig[row * a.estride + (size_t)w * a.n + col] = d;
+  }
+}
+
+// ---- counting sort with LDS-resident counters --------------------------------------------------
+// Random global atomics run at ~2e10/s on MI355X (one dword per lane in 64 different rows); the same
+// increments on LDS counters are ~100x cheaper.  A block owns (problem p, bucket range r, entry chunk k): it
+// histograms its chunk into LDS, the per-block counts are prefix-summed over k, and the scatter pass replays the
+// chunk against LDS cursors.  The order inside a bucket depends on LDS arbitration only; sums do not (EC addition
+// commutes and results are compared in canonical affine form).
+struct SortGeom {
+  size_t E;          // digit entries per problem
+  size_t estride;    // sorted-entry capacity per problem (== E)
+  size_t chunk;      // entries per chunk
+  size_t ncol, tstride;   // ROWS payload mapping: e = w*ncol + col -> point index w*tstride + col
+  int nb, RS, logRS, R, K, mode;
+};
+extern __shared__ uint32_t sort_lds[];
+
+__global__ void __launch_bounds__(1024) k_hist_lds(const int32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blockhist) {
+  const int k = blockIdx.x, r = blockIdx.y; const size_t p = blockIdx.z;
+  for (int j = threadIdx.x; j < g.RS; j += blockDim.x) sort_lds[j] = 0;
+  __syncthreads();
+  const size_t e0 = (size_t)k * g.chunk, e1 = (e0 + g.chunk < g.E) ? e0 + g.chunk : g.E;
+  const int32_t* d = dig + p * g.E;
+  for (size_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    const int v = d[e];
+    if (v == 0) continue;
+    const int b = (v < 0 ? -v : v) - 1;
+    if ((b >> g.logRS) == r) atomicAdd(&sort_lds[b & (g.RS - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* o = blockhist + ((p * g.R + r) * g.K + k) * (size_t)g.RS;
+  for (int j = threadIdx.x; j < g.RS; j += blockDim.x) o[j] = sort_lds[j];
+}
+// exclusive prefix over the K chunks of every bucket (in place) and the bucket totals
+__global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ blockhist, SortGeom g, size_t nbuckets, uint32_t* __restrict__ hist) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbuckets) return;
+  const size_t p = t / g.nb; const int b = (int)(t - p * g.nb);
+  const int r = b >> g.logRS, j = b & (g.RS - 1);
+  uint32_t* q = blockhist + ((p * g.R + r) * g.K) * (size_t)g.RS + j;
+  uint32_t run = 0;
+  for (int k = 0; k < g.K; k++) { const uint32_t v = q[(size_t)k * g.RS]; q[(size_t)k * g.RS] = run; run += v; }
+  hist[t] = run;
+}
+__global__ void __launch_bounds__(1024) k_scatter_lds(const int32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+  const int k = blockIdx.x, r = blockIdx.y; const size_t p = blockIdx.z;
+  const uint32_t* base = blockhist + ((p * g.R + r) * g.K + k) * (size_t)g.RS;
+  const uint32_t* off = offs + p * g.nb + (size_t)r * g.RS;
+  for (int j = threadIdx.x; j < g.RS; j += blockDim.x) sort_lds[j] = off[j] + base[j];
+  __syncthreads();
+  const size_t e0 = (size_t)k * g.chunk, e1 = (e0 + g.chunk < g.E) ? e0 + g.chunk : g.E;
+  const int32_t* d = dig + p * g.E;
+  uint32_t* out = sorted + p * g.estride;
+  for (size_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+    const int v = d[e];
+    if (v == 0) continue;
+    const int b = (v < 0 ? -v : v) - 1;
+    if ((b >> g.logRS) != r) continue;
+    const uint32_t pos = atomicAdd(&sort_lds[b & (g.RS - 1)], 1u);
+    uint32_t ent;
+    if (g.mode == MODE_SINGLE) ent = (uint32_t)e;
+    else { const size_t w = e / g.ncol; ent = (uint32_t)(w * g.tstride + (e - w * g.ncol)); }
+    out[pos] = ent | (v < 0 ? 0x80000000u : 0u);
   }
 }
 
@@ -132,21 +191,61 @@ struct AccCounters { uint32_t extra_count, big_count; };
 struct ExtraItem { uint32_t bucket, seg; };
 struct BigItem { uint32_t bucket, base, k; };
 
+// software-pipelined: the index two entries ahead and the point one entry ahead are in flight during each mixed add
 __device__ __forceinline__ XYZZ acc_segment(const uint32_t* __restrict__ points, const uint32_t* __restrict__ lst, uint32_t from, uint32_t to) {
   XYZZ acc = xyzz_inf();
+  if (from >= to) return acc;
+  uint32_t e_cur = lst[from];
+  uint32_t e_nxt = (from + 1 < to) ? lst[from + 1] : 0;
+  Affine p_cur = aff_load(points + 16 * (size_t)(e_cur & 0x7fffffffu));
   for (uint32_t j = from; j < to; j++) {
-    const uint32_t e = lst[j];
-    const Affine p = aff_load(points + 16 * (size_t)(e & 0x7fffffffu));
+    const uint32_t e = e_cur; const Affine p = p_cur;
+    if (j + 1 < to) {
+      e_cur = e_nxt;
+      p_cur = aff_load(points + 16 * (size_t)(e_cur & 0x7fffffffu));
+      if (j + 2 < to) e_nxt = lst[j + 2];
+    }
     xyzz_madd(acc, p, (e >> 31) != 0);
   }
   return acc;
 }
 
+// Buckets are processed in order of decreasing load (global counting sort on min(count, SEG)): the 64 lanes of a wave
+// then run chains of equal length instead of waiting for the longest of 64 Poisson draws, and the heaviest waves are
+// dispatched first so the tail of the launch is made of the lightest ones.
+__global__ void __launch_bounds__(1024) k_size_hist(const uint32_t* __restrict__ hist, size_t nbuckets, uint32_t SEG, uint32_t* __restrict__ gbins) {
+  __shared__ uint32_t bins[1026];
+  for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) bins[j] = 0;
+  __syncthreads();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < nbuckets) { const uint32_t cn = hist[t]; atomicAdd(&bins[SEG - (cn < SEG ? cn : SEG)], 1u); }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) if (bins[j]) atomicAdd(&gbins[j], bins[j]);
+}
+__global__ void __launch_bounds__(64) k_size_scan(uint32_t* __restrict__ gbins, uint32_t SEG) {
+  if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t j = 0; j <= SEG; j++) { const uint32_t v = gbins[j]; gbins[j] = run; run += v; } }
+}
+__global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restrict__ hist, size_t nbuckets, uint32_t SEG, uint32_t* __restrict__ gcur, uint32_t* __restrict__ perm) {
+  __shared__ uint32_t bins[1026];
+  __shared__ uint32_t base[1026];
+  for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) bins[j] = 0;
+  __syncthreads();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t key = 0, rank = 0;
+  if (t < nbuckets) { const uint32_t cn = hist[t]; key = SEG - (cn < SEG ? cn : SEG); rank = atomicAdd(&bins[key], 1u); }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) if (bins[j]) base[j] = atomicAdd(&gcur[j], bins[j]);
+  __syncthreads();
+  if (t < nbuckets) perm[base[key] + rank] = (uint32_t)t;
+}
+
 __global__ void __launch_bounds__(256) k_acc_first(const uint32_t* __restrict__ points, size_t nbuckets, int nb, size_t estride, uint32_t SEG,
                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
+                                                   const uint32_t* __restrict__ perm,
                                                    uint32_t* __restrict__ buckets, AccCounters* __restrict__ ctr, ExtraItem* __restrict__ extra, BigItem* __restrict__ big) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbuckets) return;
+  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t0 >= nbuckets) return;
+  const size_t t = perm[t0];
   const uint32_t cnt = hist[t];
   const uint32_t* lst = sorted + (t / nb) * estride + offs[t];
   const XYZZ acc = acc_segment(points, lst, 0, cnt < SEG ? cnt : SEG);

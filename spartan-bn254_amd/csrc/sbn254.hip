@@ -40,7 +40,8 @@ struct sbn_ctx {
   std::string err;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
-  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm;
+  int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
   // profiling
   bool prof = false;
@@ -156,7 +157,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const size_t estride = J.da.estride;
   // segment length: twice the mean bucket load (power of two, >= 32)
   size_t mean = estride / (size_t)s.nb + 1;
-  uint32_t SEG = 32; while (SEG < 2 * mean) SEG <<= 1;
+  uint32_t SEG = 32; while (SEG < 2 * mean && SEG < 1024) SEG <<= 1;
+  if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= 1024) SEG = (uint32_t)v; }
   const size_t max_extra = J.P * estride / SEG + 1;
   const size_t max_big = std::min(NB, max_extra);
   int rc;
@@ -180,15 +182,39 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   uint32_t* sorted = (uint32_t*)c->sorted.p; uint32_t* buckets = (uint32_t*)c->buckets.p;
   AccCounters* ctr = (AccCounters*)c->acc_ctr.p;
 
-  HIPCHK(c, hipMemsetAsync(hist, 0, NB * 4, c->stream));
   HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(AccCounters), c->stream));
+  // digits once, then the LDS counting sort
+  SortGeom g; memset(&g, 0, sizeof g);
+  g.E = estride; g.estride = estride; g.nb = s.nb; g.mode = J.mode; g.ncol = J.da.n; g.tstride = J.da.tstride;
+  g.RS = std::min(s.nb, c->sort_rs_max); g.logRS = 0; while ((1 << g.logRS) < g.RS) g.logRS++;
+  g.R = s.nb / g.RS;
+  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
+  g.chunk = (estride + g.K - 1) / g.K;
+  if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
+  if ((rc = ensure(c, c->digits, J.P * estride * 4))) return rc;
+  if ((rc = ensure(c, c->blockhist, J.P * (size_t)g.R * g.K * g.RS * 4))) return rc;
+  int32_t* dig = (int32_t*)c->digits.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
-  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_hist", (k_digits<MODE_SINGLE, false>), gd, 256, J.da, s, hist, sorted);
-  else LAUNCH(c, "k_digits_hist", (k_digits<MODE_ROWS, false>), gd, 256, J.da, s, hist, sorted);
+  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
+  else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
+  {
+    ProfScope _ps(c, "k_hist_lds");
+    hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, bh);
+  }
+  LAUNCH(c, "k_block_prefix", k_block_prefix, (unsigned)((NB + 255) / 256), 256, bh, g, NB, hist);
   LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, cursor, s.nb);
-  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_scatter", (k_digits<MODE_SINGLE, true>), gd, 256, J.da, s, cursor, sorted);
-  else LAUNCH(c, "k_digits_scatter", (k_digits<MODE_ROWS, true>), gd, 256, J.da, s, cursor, sorted);
-  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, buckets, ctr,
+  {
+    ProfScope _ps(c, "k_scatter_lds");
+    hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
+  }
+  // bucket order by decreasing load
+  if ((rc = ensure(c, c->size_bins, 1026 * 4))) return rc;
+  if ((rc = ensure(c, c->perm, NB * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->size_bins.p, 0, 1026 * 4, c->stream));
+  LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p);
+  LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
+  LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
+  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
          (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
@@ -309,6 +335,10 @@ int sbn_ctx_create(int device, sbn_ctx** out) {
   c->device = device;
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SBN_EHIP; }
   c->stream = c->own_stream;
+  // 128 KiB of dynamic LDS per sort block (32768 counters); gfx950 has 160 KiB per CU
+  if (hipFuncSetAttribute((const void*)k_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess &&
+      hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess) c->sort_rs_max = 32768;
+  else (void)hipGetLastError();
   *out = c;
   return SBN_OK;
 }
@@ -318,7 +348,7 @@ void sbn_ctx_destroy(sbn_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_drain(c);
   DevBuf* bufs[] = {&c->scal_canon, &c->pts_mont, &c->hist, &c->offs, &c->cursor, &c->sorted, &c->buckets, &c->red_a, &c->red_b, &c->wsum, &c->stage_scal, &c->stage_pts, &c->out_small,
-                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list};
+                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list, &c->digits, &c->blockhist, &c->size_bins, &c->perm};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (c->pin) hipHostFree(c->pin);
   for (hipEvent_t e : c->evt_pool) hipEventDestroy(e);
