@@ -404,6 +404,48 @@ __global__ void __launch_bounds__(64) k_mul_generator(const uint32_t* __restrict
   xyzz_store(out_xyzz + 32 * i, acc);
 }
 
+// ---- merging the scalars of equal bases ---------------------------------------------------------
+// The reference derives its generators as s*G with s = 1 whenever SHA3(bytes) >= r (group.rs:110-131), so ~66 % of a
+// generator set is literally the point G.  sum_j k_j P_j = sum_u (sum_{j: P_j = U_u} k_j) U_u: the scalars of equal bases
+// are added mod r first (32 B streamed per scalar, one Fr add) and the MSM runs over the unique bases only.
+// csr_off[u]..csr_off[u+1] lists the columns of unique base u; column == R means the blind column (base h).
+__device__ __forceinline__ Fr merged_load(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t row, size_t R, uint32_t col) {
+  if (col < R) return fe_load<FrP>(Z + 8 * (row * R + col));
+  if (blinds) return fe_load<FrP>(blinds + 8 * row);
+  return fe_zero<FrP>();
+}
+// small groups: one lane per (row, unique base)
+__global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                                     const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
+                                                     uint32_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L * U) return;
+  const size_t row = t / U, u = t - row * U;
+  const uint32_t a = csr_off[u], b = csr_off[u + 1];
+  if (b - a > big_threshold) return;                     // k_merge_big owns it
+  Fr acc = merged_load(Z, blinds, row, R, csr_cols[a]);
+  for (uint32_t j = a + 1; j < b; j++) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
+  fe_store<FrP>(out + 8 * t, acc);
+}
+// big groups: one wave per (row, big group)
+__global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                                  const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
+                                                  const uint32_t* __restrict__ big_list, uint32_t nbig, uint32_t* __restrict__ out) {
+  const size_t row = blockIdx.x / nbig; const uint32_t u = big_list[blockIdx.x % nbig];
+  const uint32_t a = csr_off[u], b = csr_off[u + 1];
+  Fr acc = fe_zero<FrP>();
+  for (uint32_t j = a + threadIdx.x; j < b; j += 64) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
+  // wave tree
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(acc.v[i], d, 64);
+    acc = fe_add(acc, o);
+  }
+  if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * U + u), acc);
+}
+
 // P_i = P0 + (first + i) * D : lane-local double-and-add on the 64-bit index (synthetic bases with known dlogs)
 __global__ void __launch_bounds__(64) k_arith_points(const uint32_t* __restrict__ p0d /* P0, D as XYZZ */, unsigned long long first, size_t n, uint32_t* __restrict__ out_xyzz) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

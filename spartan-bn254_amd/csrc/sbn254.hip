@@ -40,7 +40,7 @@ struct sbn_ctx {
   std::string err;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
-  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
   // profiling
@@ -55,7 +55,13 @@ struct sbn_bases {
   bool has_h = false;
   void* d_pts = nullptr;  // (n + has_h) x 64 B, Montgomery affine
   mutable std::unordered_map<int, void*> tables;   // window bits c -> W x (n + has_h) x 64 B: 2^(c w) * P_j (built on first commit)
+  // equal bases merged (commit path): unique points as their own table + CSR of the columns that map to each
+  sbn_bases* uniq = nullptr;
+  size_t U = 0; uint32_t nbig = 0;
+  void* d_csr_off = nullptr; void* d_csr_cols = nullptr; void* d_big = nullptr;
 };
+static const uint32_t MERGE_BIG = 64;
+extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);
 
 struct sbn_table {
   void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
@@ -275,6 +281,15 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
 static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
   if (L == 0) return SBN_OK;
+  if (b->uniq) {
+    // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
+    const size_t U = b->U; int rc;
+    if ((rc = ensure(c, c->merged, L * U * 32))) return rc;
+    uint32_t* m = (uint32_t*)c->merged.p;
+    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * U + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, m);
+    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, m);
+    return commit_rows_device(c, b->uniq, m, nullptr, L, U, out_xy, out_inf);
+  }
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) { memset(out_xy, 0, 64 * L); if (out_inf) memset(out_inf, 1, L); return SBN_OK; }
   BucketJob J; memset(&J, 0, sizeof J);
@@ -319,6 +334,42 @@ static int canon_scalars_dev(sbn_ctx* c, const void* d_scalars, size_t n, uint32
   return SBN_OK;
 }
 
+// Detect equal bases (keys: one byte string per point, equal keys <=> equal points) and, when enough of them repeat, attach
+// the unique-point table + CSR column lists used by the commit path.
+static int bases_build_dedupe(sbn_ctx* c, sbn_bases* b, const std::vector<std::string>& keys) {
+  const size_t tot = keys.size();
+  std::unordered_map<std::string, uint32_t> idx;
+  std::vector<uint32_t> umap(tot);
+  std::vector<uint32_t> first_col;
+  for (size_t j = 0; j < tot; j++) {
+    auto it = idx.find(keys[j]);
+    if (it == idx.end()) { uint32_t u = (uint32_t)first_col.size(); idx.emplace(keys[j], u); first_col.push_back((uint32_t)j); umap[j] = u; }
+    else umap[j] = it->second;
+  }
+  const size_t U = first_col.size();
+  if (getenv("SBN_NO_DEDUPE") || U * 10 > tot * 9) return SBN_OK;         // < 10 % repeats: not worth the extra pass
+  std::vector<uint32_t> off(U + 1, 0), cols(tot), big;
+  for (size_t j = 0; j < tot; j++) off[umap[j] + 1]++;
+  for (size_t u = 0; u < U; u++) off[u + 1] += off[u];
+  { std::vector<uint32_t> cur(off.begin(), off.end() - 1); for (size_t j = 0; j < tot; j++) cols[cur[umap[j]]++] = (uint32_t)j; }
+  for (size_t u = 0; u < U; u++) if (off[u + 1] - off[u] > MERGE_BIG) big.push_back((uint32_t)u);
+  sbn_bases* q = new sbn_bases(); q->n = U; q->has_h = false;
+  hipError_t e = hipMalloc(&q->d_pts, U * 64);
+  if (e != hipSuccess) { delete q; return fail(c, SBN_ENOMEM, "hipMalloc unique bases: %s", hipGetErrorString(e)); }
+  for (size_t u = 0; u < U; u++)
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)q->d_pts + 64 * u, (const uint8_t*)b->d_pts + 64 * (size_t)first_col[u], 64, hipMemcpyDeviceToDevice, c->stream));
+  auto up = [&](void** dst, const std::vector<uint32_t>& v) -> int {
+    hipError_t e2 = hipMalloc(dst, std::max<size_t>(4, v.size() * 4)); if (e2 != hipSuccess) return SBN_ENOMEM;
+    if (!v.empty() && hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return SBN_EHIP;
+    return SBN_OK;
+  };
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = up(&b->d_csr_off, off)) || (rc = up(&b->d_csr_cols, cols)) || (rc = up(&b->d_big, big))) { sbn_bases_free(c, q); return fail(c, rc, "dedupe tables"); }
+  b->uniq = q; b->U = U; b->nbig = (uint32_t)big.size();
+  return SBN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 extern "C" {
 
@@ -348,7 +399,7 @@ void sbn_ctx_destroy(sbn_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_drain(c);
   DevBuf* bufs[] = {&c->scal_canon, &c->pts_mont, &c->hist, &c->offs, &c->cursor, &c->sorted, &c->buckets, &c->red_a, &c->red_b, &c->wsum, &c->stage_scal, &c->stage_pts, &c->out_small,
-                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list, &c->digits, &c->blockhist, &c->size_bins, &c->perm};
+                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list, &c->digits, &c->blockhist, &c->size_bins, &c->perm, &c->merged};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (c->pin) hipHostFree(c->pin);
   for (hipEvent_t e : c->evt_pool) hipEventDestroy(e);
@@ -378,10 +429,18 @@ int sbn_bases_upload(sbn_ctx* c, const uint8_t* G_xy, size_t n, const uint8_t* h
     LAUNCH(c, "k_points_to_mont", k_points_to_mont, (unsigned)((tot + 255) / 256), 256, (const uint32_t*)b->d_pts, (uint32_t*)b->d_pts, tot);
   LAUNCHCHK(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  {
+    std::vector<std::string> keys(tot);
+    for (size_t j = 0; j < n; j++) keys[j].assign((const char*)G_xy + 64 * j, 64);
+    if (h_xy) keys[n].assign((const char*)h_xy, 64);
+    int rc = bases_build_dedupe(c, b, keys);
+    if (rc) { sbn_bases_free(c, b); return rc; }
+  }
   *out = b;
   return SBN_OK;
 }
-void sbn_bases_free(sbn_ctx* c, sbn_bases* b) { if (!b) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (b->d_pts) hipFree(b->d_pts); for (auto& kv : b->tables) hipFree(kv.second); delete b; }
+void sbn_bases_free(sbn_ctx* c, sbn_bases* b) { if (!b) return; if (b->uniq) { sbn_bases_free(c, b->uniq); b->uniq = nullptr; }
+  if (b->d_csr_off) hipFree(b->d_csr_off); if (b->d_csr_cols) hipFree(b->d_csr_cols); if (b->d_big) hipFree(b->d_big); if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (b->d_pts) hipFree(b->d_pts); for (auto& kv : b->tables) hipFree(kv.second); delete b; }
 size_t sbn_bases_len(const sbn_bases* b) { return b ? b->n : 0; }
 
 int sbn_msm_bases_dev(sbn_ctx* c, const sbn_bases* b, const void* d_scalars, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
@@ -522,6 +581,11 @@ int sbn_gens_new(sbn_ctx* c, size_t n, const uint8_t* label, size_t label_len, u
   LAUNCHCHK(c);
   if (out_xy) HIPCHK(c, hipMemcpyAsync(out_xy, d_xy, tot * 64, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  {
+    std::vector<std::string> keys(tot);     // equal discrete logs <=> equal points
+    for (size_t j = 0; j < tot; j++) keys[j].assign((const char*)&dl[32 * j], 32);
+    if ((rc = bases_build_dedupe(c, b, keys))) { sbn_bases_free(c, b); return rc; }
+  }
   *out = b;
   return SBN_OK;
 }
