@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="msm: log2 of the points per GPU")
     ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows per GPU")
     ap.add_argument("--cols", type=int, default=8192, help="hyrax: matrix columns")
+    ap.add_argument("--inflight", type=int, default=2, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,12 +101,15 @@ def main():
     from spartan_bn254_amd import sharding
     import oracle_lib as ol          # the checker and the cpu_baseline leg only
     ctx = sbn.Context(local_rank)    # raises if the HIP library / device is missing: no fallback
+    M = max(1, args.inflight)
+    ctxs = [ctx] + [sbn.Context(local_rank) for _ in range(M - 1)]     # one HIP stream + workspace per step in flight
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ctx.sync()
+        for cx in ctxs:
+            cx.sync()
 
     G_XY = bytes([1]) + bytes(31) + bytes([2]) + bytes(31)
     cpu_baseline = None
@@ -117,11 +121,22 @@ def main():
         bases = ctx.bases_synthetic(n, first, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
         torch.cuda.synchronize()
 
+        def local_step(cx):
+            return cx.msm_bases_dev(bases, d_scal.data_ptr(), n)
+
+        def finish(parts):
+            """one RCCL all-gather for the partial sums of the steps that just completed, then the local folds"""
+            if world == 1:
+                return parts
+            xy, _ = zip(*parts)
+            t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(dev)
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            allb = [o.cpu().numpy().tobytes() for o in outs]
+            return [sbn.g1_sum(b"".join(a[64 * j:64 * j + 64] for a in allb)) for j in range(len(parts))]
+
         def step():
-            part, inf = ctx.msm_bases_dev(bases, d_scal.data_ptr(), n)
-            if world > 1:
-                return sharding.allgather_fold(part, device=dev)
-            return part, inf
+            return finish([local_step(ctx)])[0]
 
         # parity gate: partial == (sum k_i s_i) G, exact
         part, _ = ctx.msm_bases_dev(bases, d_scal.data_ptr(), n)
@@ -149,8 +164,14 @@ def main():
         Z[(3 * L // 4) * Rc:] = 0                                  # rows 3072.. are zero padding (hyrax.rs:245)
         torch.cuda.synchronize()
 
+        def local_step(cx):
+            return cx.commit_rows_dev(bases, Z.data_ptr(), 0, L, Rc)
+
+        def finish(parts):
+            return parts
+
         def step():
-            return ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, Rc)
+            return local_step(ctx)
 
         out, infs = step()
         gxy, _ = ol.gens_new(Rc, b"gens_r1cs_eval")
@@ -165,17 +186,44 @@ def main():
         metric = "msm_points_per_s"
         unit = "points/s"
 
-    for _ in range(args.warmup):
-        step()
-    ctx.prof_enable(True); ctx.prof_reset()
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=M)
+
+    def run_steps(count):
+        """`count` steps with up to M in flight.  N = 1: each stream free-runs its share.  N > 1: groups of M local steps,
+        then one collective per group issued from this thread (collectives must be ordered identically on every rank)."""
+        if M == 1:
+            for _ in range(count):
+                step()
+            return
+        if world == 1:
+            shares = [count // M + (1 if j < count % M else 0) for j in range(M)]
+            futs = [pool.submit(lambda cx=cx, k=k: [local_step(cx) for _ in range(k)]) for cx, k in zip(ctxs, shares)]
+            for f in futs:
+                f.result()
+            return
+        done = 0
+        while done < count:
+            g = min(M, count - done)
+            futs = [pool.submit(local_step, ctxs[j]) for j in range(g)]
+            finish([f.result() for f in futs])
+            done += g
+
+    for cx in ctxs:                       # every stream's workspace is sized before the timed region
+        local_step(cx)
+    run_steps(args.warmup)
+    for cx in ctxs:
+        cx.prof_enable(True); cx.prof_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    prof = ctx.prof_get()
-    ctx.prof_enable(False)
+    prof = {}
+    for cx in ctxs:
+        for k, (ms, cnt) in cx.prof_get().items():
+            a, b = prof.get(k, (0.0, 0)); prof[k] = (a + ms, b + cnt)
+        cx.prof_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,13 +267,15 @@ def main():
         line = {"metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u32", "data": "synthetic",
-                "config": {"workload": workload, "units_per_step_per_gpu": units_per_step,
+                "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "steps_in_flight": M,
                            "sharding": "base-point ranges + one RCCL all-gather of 64-B partial sums" if args.workload == "msm" else "independent matrices per GPU, no collective",
                            "parity": "bit-exact vs discrete-log oracle, checked before timing"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kern}
         print(json.dumps(line), flush=True)
     bases.free()
-    ctx.close()
+    pool.shutdown()
+    for cx in ctxs:
+        cx.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -85,8 +85,9 @@ __device__ __forceinline__ void xyzz_madd(XYZZ& acc, const Affine& q_in, bool ne
   acc.X = X3; acc.Y = Y3; acc.ZZ = fe_mul(acc.ZZ, PP); acc.ZZZ = fe_mul(acc.ZZZ, PPP);
 }
 
-// a + b, both XYZZ.  12M + 2S on the common path.
-__device__ __noinline__ XYZZ xyzz_add(const XYZZ& a, const XYZZ& b) {
+// a + b, both XYZZ.  12M + 2S on the common path.  The inlined form is for the latency-bound reduction kernels (a call
+// passes both 128-byte operands through scratch); xyzz_add is the out-of-line copy for code-size-sensitive callers.
+__device__ __forceinline__ XYZZ xyzz_add_inl(const XYZZ& a, const XYZZ& b) {
   if (xyzz_is_inf(a)) return b;
   if (xyzz_is_inf(b)) return a;
   Fq U1 = fe_mul(a.X, b.ZZ), U2 = fe_mul(b.X, a.ZZ), S1 = fe_mul(a.Y, b.ZZZ), S2 = fe_mul(b.Y, a.ZZZ);
@@ -103,6 +104,7 @@ __device__ __noinline__ XYZZ xyzz_add(const XYZZ& a, const XYZZ& b) {
   r.ZZZ = fe_mul(fe_mul(a.ZZZ, b.ZZZ), PPP);
   return r;
 }
+__device__ __noinline__ XYZZ xyzz_add(const XYZZ& a, const XYZZ& b) { return xyzz_add_inl(a, b); }
 
 // canonical affine (Montgomery coordinates) from XYZZ: one inversion
 __device__ __noinline__ Affine xyzz_to_affine(const XYZZ& p) {

@@ -41,6 +41,7 @@ struct sbn_ctx {
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
   DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
+  bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
   // profiling
@@ -177,7 +178,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
   if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
   if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
-  int L = s.nb / 64; if (L > 8) L = 8; if (L < 1) L = 1;
+  int L = s.nb / 64; if (L > 4) L = 4; if (L < 1) L = 1;
+  if (const char* el = getenv("SBN_RED_L")) { int v = atoi(el); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= s.nb / 64) L = v; }
   int logL = 0; while ((1 << logL) < L) logL++;
   const int chunks = s.nb / (64 * L);                     // per problem, >= 1
   if ((rc = ensure(c, c->red_a, J.P * chunks * 256))) return rc;
@@ -194,7 +196,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   g.E = estride; g.estride = estride; g.nb = s.nb; g.mode = J.mode; g.ncol = J.da.n; g.tstride = J.da.tstride;
   g.RS = std::min(s.nb, c->sort_rs_max); g.logRS = 0; while ((1 << g.logRS) < g.RS) g.logRS++;
   g.R = s.nb / g.RS;
-  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
+  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); if (J.mode == MODE_ROWS) g.K = 1; }
   g.chunk = (estride + g.K - 1) / g.K;
   if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
   if ((rc = ensure(c, c->digits, J.P * estride * 4))) return rc;
@@ -203,15 +205,21 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
   if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
   else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
-  {
-    ProfScope _ps(c, "k_hist_lds");
-    hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, bh);
-  }
-  LAUNCH(c, "k_block_prefix", k_block_prefix, (unsigned)((NB + 255) / 256), 256, bh, g, NB, hist);
-  LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, cursor, s.nb);
-  {
-    ProfScope _ps(c, "k_scatter_lds");
-    hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
+  const size_t rows_lds = sort_rows_lds_bytes(s.nb);
+  if (J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT")) {
+    ProfScope _ps(c, "k_sort_rows");
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const int32_t*)dig, g, hist, offs, sorted);
+  } else {
+    {
+      ProfScope _ps(c, "k_hist_lds");
+      hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, bh);
+    }
+    LAUNCH(c, "k_block_prefix", k_block_prefix, (unsigned)((NB + 255) / 256), 256, bh, g, NB, hist);
+    LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, cursor, s.nb);
+    {
+      ProfScope _ps(c, "k_scatter_lds");
+      hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
+    }
   }
   // bucket order by decreasing load
   if ((rc = ensure(c, c->size_bins, 1026 * 4))) return rc;
@@ -389,6 +397,8 @@ int sbn_ctx_create(int device, sbn_ctx** out) {
   // 128 KiB of dynamic LDS per sort block (32768 counters); gfx950 has 160 KiB per CU
   if (hipFuncSetAttribute((const void*)k_hist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess &&
       hipFuncSetAttribute((const void*)k_scatter_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4) == hipSuccess) c->sort_rs_max = 32768;
+  else (void)hipGetLastError();
+  if (hipFuncSetAttribute((const void*)k_sort_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess) c->sort_rows_ok = true;
   else (void)hipGetLastError();
   *out = c;
   return SBN_OK;

@@ -184,8 +184,8 @@ def test_full_size_properties_2p20(ctx, ol, pr):
         carry = torch.zeros(n, dtype=torch.int64, device="cuda")
         for j in range(8):
             v = ks[:, j] + carry; ks[:, j] = v & 0xffffffff; carry = v >> 32
-        ks32 = ks.to(torch.int32).contiguous()
-        # int32 view of values >= 2^31 wraps correctly for the raw bytes
+        ks32 = ks.to(torch.int32).contiguous()          # values >= 2^31 wrap to the same 32 raw bits
+        torch.cuda.synchronize()                         # the library runs on its own stream, not torch's
         os_, _ = ctx.msm_bases_dev(b, ks32.data_ptr(), n)
         assert os_ == ol.g1_add(o1, o2)
         # additivity over base ranges == the sharded path
