@@ -65,10 +65,22 @@ def splitmix_scalars(n, seed):
     return limbs.tobytes()
 
 
-def fr_dot_arith(ol, scalars, first, n):
-    """sum_i k_i * (S0 + (first+i)*DSTEP) mod r, via the oracle's Fr dot product (checker only)"""
-    dl = b"".join(((S0 + (first + i) * DSTEP) % R_MOD).to_bytes(32, "little") for i in range(n))
-    return ol.fr_dot(scalars, dl)
+def fr_dot_arith(scalars, first, n):
+    """sum_i k_i * (S0 + (first+i)*DSTEP) mod r  =  S0*sum(k_i) + DSTEP*sum((first+i)*k_i), exact, vectorised:
+    the scalars are split into 16-bit digits so that every numpy partial sum stays below 2^64."""
+    k16 = np.frombuffer(scalars, dtype=np.uint16).reshape(n, 16).astype(np.uint64)       # little-endian 16-bit digits
+    idx = np.arange(n, dtype=np.uint64)
+    ilo, ihi = idx & np.uint64(0xFFFF), idx >> np.uint64(16)                             # n <= 2^32
+    sum_k = 0; sum_ik = 0
+    for j in range(16):
+        col = k16[:, j]
+        sj = int(col.sum(dtype=np.uint64))                      # < 2^16 * n
+        lo = int((col * ilo).sum(dtype=np.uint64))              # < 2^32 * n  (n <= 2^31)
+        hi = int((col * ihi).sum(dtype=np.uint64))
+        sum_k += sj << (16 * j)
+        sum_ik += (lo + (hi << 16)) << (16 * j)
+    tot = (S0 * sum_k + DSTEP * (sum_ik + first * sum_k)) % R_MOD
+    return tot.to_bytes(32, "little")
 
 
 def main():
@@ -91,18 +103,27 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices and the
+    # 64-byte partials travel as CPU tensors); the driver's runs use the default: "nccl", which is RCCL on ROCm.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     sbn = load_pkg()
     from spartan_bn254_amd import sharding
     import oracle_lib as ol          # the checker and the cpu_baseline leg only
-    ctx = sbn.Context(local_rank)    # raises if the HIP library / device is missing: no fallback
+    ctx = sbn.Context(dev_index)    # raises if the HIP library / device is missing: no fallback
     M = max(1, args.inflight)
-    ctxs = [ctx] + [sbn.Context(local_rank) for _ in range(M - 1)]     # one HIP stream + workspace per step in flight
+    ctxs = [ctx] + [sbn.Context(dev_index) for _ in range(M - 1)]     # one HIP stream + workspace per step in flight
 
     def barrier():
         if world > 1:
@@ -129,7 +150,7 @@ def main():
             if world == 1:
                 return parts
             xy, _ = zip(*parts)
-            t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(dev)
+            t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(coll_dev)
             outs = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(outs, t)
             allb = [o.cpu().numpy().tobytes() for o in outs]
@@ -140,7 +161,7 @@ def main():
 
         # parity gate: partial == (sum k_i s_i) G, exact
         part, _ = ctx.msm_bases_dev(bases, d_scal.data_ptr(), n)
-        want = ol.g1_mul(G_XY, fr_dot_arith(ol, scal, first, n))
+        want = ol.g1_mul(G_XY, fr_dot_arith(scal, first, n))
         if part != want:
             raise SystemExit(f"rank {rank}: GPU MSM result differs from the discrete-log oracle")
         total, _ = step()
@@ -225,7 +246,7 @@ def main():
             a, b = prof.get(k, (0.0, 0)); prof[k] = (a + ms, b + cnt)
         cx.prof_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -267,7 +288,7 @@ def main():
         line = {"metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u32", "data": "synthetic",
-                "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "steps_in_flight": M,
+                "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "steps_in_flight": M, "collective_backend": backend if world > 1 else None,
                            "sharding": "base-point ranges + one RCCL all-gather of 64-B partial sums" if args.workload == "msm" else "independent matrices per GPU, no collective",
                            "parity": "bit-exact vs discrete-log oracle, checked before timing"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kern}

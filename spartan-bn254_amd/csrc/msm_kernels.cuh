@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
 // more (skewed scalars, or the short top window of a single MSM whose few buckets hold n/2^tb points each) posts its
 // other segments to a work list that k_acc_extra spreads over the whole chip, and k_acc_merge folds the partials
 // with one wave per oversized bucket.  No lane ever runs a chain longer than SEG mixed adds (+ a short merge).
+constexpr uint32_t ACC_SEG_MAX = 8192;   // longest chain one lane runs before a bucket is cut into segments
 struct AccCounters { uint32_t extra_count, big_count; };
 struct ExtraItem { uint32_t bucket, seg; };
 struct BigItem { uint32_t bucket, base, k; };
@@ -306,7 +307,7 @@ __device__ __forceinline__ XYZZ acc_segment(const uint32_t* __restrict__ points,
 // then run chains of equal length instead of waiting for the longest of 64 Poisson draws, and the heaviest waves are
 // dispatched first so the tail of the launch is made of the lightest ones.
 __global__ void __launch_bounds__(1024) k_size_hist(const uint32_t* __restrict__ hist, size_t nbuckets, uint32_t SEG, uint32_t* __restrict__ gbins) {
-  __shared__ uint32_t bins[1026];
+  __shared__ uint32_t bins[ACC_SEG_MAX + 2];
   for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) bins[j] = 0;
   __syncthreads();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,8 +319,8 @@ __global__ void __launch_bounds__(64) k_size_scan(uint32_t* __restrict__ gbins, 
   if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t j = 0; j <= SEG; j++) { const uint32_t v = gbins[j]; gbins[j] = run; run += v; } }
 }
 __global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restrict__ hist, size_t nbuckets, uint32_t SEG, uint32_t* __restrict__ gcur, uint32_t* __restrict__ perm) {
-  __shared__ uint32_t bins[1026];
-  __shared__ uint32_t base[1026];
+  __shared__ uint32_t bins[ACC_SEG_MAX + 2];
+  __shared__ uint32_t base[ACC_SEG_MAX + 2];
   for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) bins[j] = 0;
   __syncthreads();
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

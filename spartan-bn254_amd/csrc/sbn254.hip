@@ -136,11 +136,13 @@ static MsmShape make_shape(int c) {
 // Window size from a cost model in modular products: `terms`*W mixed adds (10 each) into `sets` bucket sets of 2^(c-1)
 // buckets, each bucket costing ~2 full adds (14 each) in the running-sum reduction (x2 for the wave-level part).
 // SBN_MSM_C overrides for experiments.
-static MsmShape choose_shape(size_t terms, bool shared_bucket_set) {
+static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax) {
   const char* env = getenv("SBN_MSM_C");
   if (env && atoi(env) >= 7 && atoi(env) <= 22) return make_shape(atoi(env));
   double best = 1e300; int bc = 7;
-  for (int c = 7; c <= 20; c++) {
+  // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
+  // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows.
+  for (int c = 7; c <= cmax; c++) {
     MsmShape s = make_shape(c);
     double sets = shared_bucket_set ? 1.0 : (double)s.W;
     double cost = (double)terms * s.W * 10.0 + sets * s.nb * 56.0;
@@ -164,8 +166,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const size_t estride = J.da.estride;
   // segment length: twice the mean bucket load (power of two, >= 32)
   size_t mean = estride / (size_t)s.nb + 1;
-  uint32_t SEG = 32; while (SEG < 2 * mean && SEG < 1024) SEG <<= 1;
-  if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= 1024) SEG = (uint32_t)v; }
+  uint32_t SEG = 32; while (SEG < 2 * mean && SEG < ACC_SEG_MAX) SEG <<= 1;
+  if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
   const size_t max_extra = J.P * estride / SEG + 1;
   const size_t max_big = std::min(NB, max_extra);
   int rc;
@@ -222,9 +224,9 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
     }
   }
   // bucket order by decreasing load
-  if ((rc = ensure(c, c->size_bins, 1026 * 4))) return rc;
+  if ((rc = ensure(c, c->size_bins, (ACC_SEG_MAX + 2) * 4))) return rc;
   if ((rc = ensure(c, c->perm, NB * 4))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->size_bins.p, 0, 1026 * 4, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->size_bins.p, 0, (ACC_SEG_MAX + 2) * 4, c->stream));
   LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p);
   LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
   LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
@@ -251,7 +253,7 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
   if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
   if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
   BucketJob J; memset(&J, 0, sizeof J);
-  J.mode = MODE_SINGLE; J.s = choose_shape(n, false); J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
+  J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
   J.da.scalars = d_scal; J.da.n = n; J.da.estride = n;
   int rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;
@@ -301,7 +303,7 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) { memset(out_xy, 0, 64 * L); if (out_inf) memset(out_inf, 1, L); return SBN_OK; }
   BucketJob J; memset(&J, 0, sizeof J);
-  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true); J.P = L; J.threads = L * ncol;
+  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16); J.P = L; J.threads = L * ncol;
   const size_t npts = b->n + (b->has_h ? 1 : 0);
   if ((size_t)J.s.W * npts > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: table index overflow");
   int rc; const uint32_t* tab;
