@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows per GPU")
     ap.add_argument("--cols", type=int, default=8192, help="hyrax: matrix columns")
     ap.add_argument("--inflight", type=int, default=2, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
+    ap.add_argument("--fixed-base", action="store_true", help="msm: treat the resident bases as fixed generators (per-window multiples precomputed once, "
+                    "as the commit path does): sbn_commit_rows with L = 1 instead of sbn_msm_bases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -143,6 +145,9 @@ def main():
         torch.cuda.synchronize()
 
         def local_step(cx):
+            if args.fixed_base:
+                xy, infs = cx.commit_rows_dev(bases, d_scal.data_ptr(), 0, 1, n)
+                return xy, bool(infs[0])
             return cx.msm_bases_dev(bases, d_scal.data_ptr(), n)
 
         def finish(parts):
@@ -160,7 +165,7 @@ def main():
             return finish([local_step(ctx)])[0]
 
         # parity gate: partial == (sum k_i s_i) G, exact
-        part, _ = ctx.msm_bases_dev(bases, d_scal.data_ptr(), n)
+        part, _ = local_step(ctx)
         want = ol.g1_mul(G_XY, fr_dot_arith(scal, first, n))
         if part != want:
             raise SystemExit(f"rank {rank}: GPU MSM result differs from the discrete-log oracle")
@@ -173,7 +178,8 @@ def main():
         units_per_step = n
         alg_bytes_per_launch = 96.0 * n                            # 32 B scalar + 64 B affine base per point
         dominant = "k_acc_first"
-        workload = f"synthetic BN254 G1 MSM, 2^{args.log_n} uniform scalars x distinct bases per GPU, inputs resident in HBM"
+        workload = f"synthetic BN254 G1 MSM, 2^{args.log_n} uniform scalars x distinct bases per GPU, inputs resident in HBM" + (
+            " (fixed-base mode: per-window multiples of the bases precomputed once)" if args.fixed_base else "")
         metric = "msm_points_per_s"
         unit = "points/s"
     else:

@@ -156,19 +156,17 @@ __global__ void __launch_bounds__(1024) k_scatter_lds(const int32_t* __restrict_
       out[pos] = (uint32_t)e | (v < 0 ? 0x80000000u : 0u);
     }
   } else {
-    // ROWS (K == 1): walk (window, column) so the table index w*tstride + col needs no division
-    const uint32_t ncol = (uint32_t)g.ncol, W = (uint32_t)(g.E / g.ncol);
-    for (uint32_t w = 0; w < W; w++) {
-      const int32_t* dw = d + (size_t)w * ncol;
-      const uint32_t tb = w * (uint32_t)g.tstride;
-      for (uint32_t col = threadIdx.x; col < ncol; col += blockDim.x) {
-        const int v = dw[col];
-        if (v == 0) continue;
-        const int b = (v < 0 ? -v : v) - 1;
-        if ((b >> g.logRS) != r) continue;
-        const uint32_t pos = atomicAdd(&sort_lds[b & (g.RS - 1)], 1u);
-        out[pos] = (tb + col) | (v < 0 ? 0x80000000u : 0u);
-      }
+    // ROWS: entry e = w*ncol + col -> table index w*tstride + col (E < 2^31, so the division is 32-bit)
+    const uint32_t ncol = (uint32_t)g.ncol, ts = (uint32_t)g.tstride;
+    const uint32_t e0 = (uint32_t)((size_t)k * g.chunk), e1 = (uint32_t)((e0 + g.chunk < g.E) ? e0 + g.chunk : g.E);
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+      const int v = d[e];
+      if (v == 0) continue;
+      const int b = (v < 0 ? -v : v) - 1;
+      if ((b >> g.logRS) != r) continue;
+      const uint32_t pos = atomicAdd(&sort_lds[b & (g.RS - 1)], 1u);
+      const uint32_t w = e / ncol;
+      out[pos] = (w * ts + (e - w * ncol)) | (v < 0 ? 0x80000000u : 0u);
     }
   }
 }
@@ -389,12 +387,25 @@ __device__ __forceinline__ XYZZ xyzz_mul_pow2(XYZZ v, int k) {
   return v;
 }
 
-// one wave per oversized bucket: bucket += sum of its k extra partials (lane-strided chains, then a wave tree)
+// folding the extra partials back into their bucket: a bucket with few of them is finished by one lane (64 buckets per
+// wave), a bucket with many by one whole wave (lane-strided chains, then a wave tree)
+constexpr uint32_t MERGE_LANE_MAX = 12;
+__global__ void __launch_bounds__(256) k_acc_merge_few(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets) {
+  const uint32_t total = ctr->big_count;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const BigItem bi = big[i];
+    if (bi.k > MERGE_LANE_MAX) continue;
+    XYZZ acc = xyzz_load(buckets + 32 * (size_t)bi.bucket);
+    for (uint32_t j = 0; j < bi.k; j++) acc = xyzz_add(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
+    xyzz_store(buckets + 32 * (size_t)bi.bucket, acc);
+  }
+}
 __global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets) {
   const int lane = threadIdx.x;
   const uint32_t total = ctr->big_count;
   for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
     const BigItem bi = big[i];
+    if (bi.k <= MERGE_LANE_MAX) continue;
     XYZZ acc = (lane == 0) ? xyzz_load(buckets + 32 * (size_t)bi.bucket) : xyzz_inf();
     for (uint32_t j = lane; j < bi.k; j += 64) acc = xyzz_add_inl(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
     acc = wave_sum(acc, lane);

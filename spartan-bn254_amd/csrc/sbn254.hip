@@ -167,6 +167,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   // segment length: twice the mean bucket load (power of two, >= 32)
   size_t mean = estride / (size_t)s.nb + 1;
   uint32_t SEG = 32; while (SEG < 2 * mean && SEG < ACC_SEG_MAX) SEG <<= 1;
+  // enough segments to fill the chip when a problem has few, heavily loaded buckets (one row, many columns)
+  { const size_t total = J.P * estride; uint32_t cap = 32; while ((size_t)cap * 262144 < total && cap < ACC_SEG_MAX) cap <<= 1; if (SEG > cap) SEG = cap; }
   if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
   const size_t max_extra = J.P * estride / SEG + 1;
   const size_t max_big = std::min(NB, max_extra);
@@ -198,7 +200,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   g.E = estride; g.estride = estride; g.nb = s.nb; g.mode = J.mode; g.ncol = J.da.n; g.tstride = J.da.tstride;
   g.RS = std::min(s.nb, c->sort_rs_max); g.logRS = 0; while ((1 << g.logRS) < g.RS) g.logRS++;
   g.R = s.nb / g.RS;
-  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); if (J.mode == MODE_ROWS) g.K = 1; }
+  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
   g.chunk = (estride + g.K - 1) / g.K;
   if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
   if ((rc = ensure(c, c->digits, J.P * estride * 4))) return rc;
@@ -233,6 +235,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
          (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
+  LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
   LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;

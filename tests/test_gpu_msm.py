@@ -157,6 +157,52 @@ def test_commit_argument_errors(ctx, ol, sbn):
         b.free(); nb.free()
 
 
+S0 = 0x1234567890abcdef1234567890abcdef
+DSTEP = 0x0fedcba987654321
+
+
+def _arith_dlogs(pr, first, n):
+    return b"".join(((S0 + (first + i) * DSTEP) % pr.R).to_bytes(32, "little") for i in range(n))
+
+
+@pytest.mark.parametrize("L,R", [(1, 20000), (3, 3000), (2, 9000)])
+def test_commit_rows_distinct_bases_paths(ctx, ol, pr, L, R):
+    """rows with DISTINCT bases (no merging of equal bases): the generic chunked sort (1 x 20000: one problem, many
+    entries), the fused per-row sort with a constant row (one bucket per window holds every column: staging overflow
+    path) and a row of tiny scalars."""
+    b = ctx.bases_synthetic(R, 5, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    try:
+        dl = _arith_dlogs(pr, 5, R)
+        assert ctx.bases_download(b, 0, 3) == ol.g1_mul_gen_batch(dl[:96], 1)
+        Z = bytearray(rand_scalars(L * R, 1000 + R))
+        if L >= 2:
+            Z[32 * R:64 * R] = Z[32 * R:32 * R + 32] * R                                   # constant row
+        if L >= 3:
+            Z[64 * R:96 * R] = b"".join(int(i % 5).to_bytes(32, "little") for i in range(R))  # tiny scalars
+        Z = bytes(Z)
+        out, infs = ctx.commit_rows(b, Z, None, L, R)
+        G = pr.point_to_xy(pr.G)
+        for i in range(L):
+            assert out[64 * i:64 * i + 64] == ol.g1_mul(G, ol.fr_dot(Z[32 * R * i:32 * R * (i + 1)], dl)), i
+    finally:
+        b.free()
+
+
+def test_msm_large_skew(ctx, ol, pr):
+    """2^17 terms, every scalar equal: each window has ONE bucket with 131072 entries (segments + wave merges at scale)"""
+    n = 1 << 17
+    b = ctx.bases_synthetic(n, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    try:
+        dl = _arith_dlogs(pr, 0, n)
+        k = rand_scalars(1, 3) * n
+        assert ctx.msm_bases(b, k)[0] == ol.g1_mul(pr.point_to_xy(pr.G), ol.fr_dot(k, dl))
+        two = rand_scalars(2, 4)
+        k2 = (two[:32] * (n // 2)) + (two[32:] * (n // 2))                                  # two distinct values
+        assert ctx.msm_bases(b, k2)[0] == ol.g1_mul(pr.point_to_xy(pr.G), ol.fr_dot(k2, dl))
+    finally:
+        b.free()
+
+
 def _dev_scalars(torch, n, seed):
     g = torch.Generator(device="cuda"); g.manual_seed(seed)
     x = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int32, device="cuda", generator=g)
