@@ -122,6 +122,13 @@ int sbn_sc_eval_r1cs(sbn_ctx* ctx, const sbn_table* tau, const sbn_table* Az, co
                      uint8_t out[96]);
 /* prove_quad inner loop, comb = z*ABC (sumcheck.rs:691-699; r1csproof.rs:389-390): out = e0,e2 */
 int sbn_sc_eval_quad(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* ABC, uint8_t out[64]);
+/* Fused round: bind every distinct table among the arguments to r (bound_poly_var_top, as sumcheck.rs:148-150 / 289-299 /
+ * 551-554 / 715-716 do after each challenge) AND return the NEXT round's sums on the bound tables — the same values the
+ * separate bind + eval calls give, in one pass over the data.  Needs len >= 4.  Argument order as the eval calls. */
+int sbn_sc_bind_eval_cubic_batched(sbn_ctx* ctx, sbn_table* const* A, sbn_table* const* B, sbn_table* const* C, size_t count,
+                                   const uint8_t r[32], uint8_t* out /* count x 96 */);
+int sbn_sc_bind_eval_r1cs(sbn_ctx* ctx, sbn_table* tau, sbn_table* Az, sbn_table* Bz, sbn_table* Cz, const uint8_t r[32], uint8_t out[96]);
+int sbn_sc_bind_eval_quad(sbn_ctx* ctx, sbn_table* Z, sbn_table* ABC, const uint8_t r[32], uint8_t out[64]);
 /* EqPolynomial::evals (hyrax.rs:355-369) built on the device */
 int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
 

@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = [
     "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_factored_lens",
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
+    "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
     "sbn_eq_evals", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
@@ -256,6 +257,17 @@ class Context:
 
     def sc_eval_quad(self, Z, ABC):
         out = (C.c_uint8 * 64)(); self._chk(lib().sbn_sc_eval_quad(self.h, Z.h, ABC.h, out), "sbn_sc_eval_quad"); return bytes(out)
+
+    def sc_bind_eval_cubic_batched(self, As, Bs, Cs, r):
+        k = len(As); mk = lambda ts: (C.c_void_p * k)(*[t.h for t in ts])
+        out = (C.c_uint8 * (96 * k))()
+        self._chk(lib().sbn_sc_bind_eval_cubic_batched(self.h, mk(As), mk(Bs), mk(Cs), C.c_size_t(k), _ptr(r), out), "sbn_sc_bind_eval_cubic_batched"); return bytes(out)
+
+    def sc_bind_eval_r1cs(self, T, A, B, Cc, r):
+        out = (C.c_uint8 * 96)(); self._chk(lib().sbn_sc_bind_eval_r1cs(self.h, T.h, A.h, B.h, Cc.h, _ptr(r), out), "sbn_sc_bind_eval_r1cs"); return bytes(out)
+
+    def sc_bind_eval_quad(self, Z, ABC, r):
+        out = (C.c_uint8 * 64)(); self._chk(lib().sbn_sc_bind_eval_quad(self.h, Z.h, ABC.h, _ptr(r), out), "sbn_sc_bind_eval_quad"); return bytes(out)
 
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()

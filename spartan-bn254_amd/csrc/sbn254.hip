@@ -66,6 +66,7 @@ extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);
 
 struct sbn_table {
   void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
+  void* d2 = nullptr; size_t cap2 = 0;     // second buffer for the fused (out-of-place) bind
 };
 
 static int fail(sbn_ctx* c, int code, const char* fmt, ...) {
@@ -670,7 +671,7 @@ int sbn_table_from_dev(sbn_ctx* c, const void* Z_dev, size_t len, uint32_t flags
   std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
   return table_make(c, Z_dev, false, len, flags, out);
 }
-void sbn_table_free(sbn_ctx* c, sbn_table* t) { if (!t) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (t->d && t->owned) hipFree(t->d); delete t; }
+void sbn_table_free(sbn_ctx* c, sbn_table* t) { if (!t) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (t->d && t->owned) hipFree(t->d); if (t->d2) hipFree(t->d2); delete t; }
 size_t sbn_table_len(const sbn_table* t) { return t ? t->len : 0; }
 int sbn_table_download(sbn_ctx* c, const sbn_table* t, uint8_t* out) {
   if (!c || !t || !out) return SBN_EINVAL;
@@ -778,6 +779,75 @@ int sbn_sc_eval_quad(sbn_ctx* c, const sbn_table* Z, const sbn_table* ABC, uint8
   std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
   const sbn_table* const* cols[2] = {&Z, &ABC};
   return sc_eval_common<KIND_QUAD>(c, cols, 2, 1, out);
+}
+}  // extern "C"
+template <int KIND>
+static int sc_bind_eval_common(sbn_ctx* c, sbn_table* const* const* cols, int ncols, size_t count, const uint8_t r[32], uint8_t* out) {
+  const size_t len = cols[0][0]->len;
+  for (int j = 0; j < ncols; j++) for (size_t i = 0; i < count; i++) {
+    if (!cols[j][i]) return SBN_EINVAL;
+    if (cols[j][i]->len != len) return fail(c, SBN_EINVAL, "sumcheck bind+eval: tables differ in length");
+  }
+  if (len < 4) return fail(c, SBN_EINVAL, "sumcheck bind+eval needs len >= 4 (use sbn_bind_top for the last round)");
+  const size_t q = len / 4;
+  int rc;
+  if ((rc = upload_r_mont(c, r))) return rc;
+  if ((rc = ensure(c, c->sc_args, count * sizeof(ScFusedArgs)))) return rc;
+  if ((rc = ensure_pin(c, 4096 + count * sizeof(ScFusedArgs) + count * 96))) return rc;
+  // every distinct table gets exactly one writer; its second buffer receives the bound half
+  std::vector<sbn_table*> distinct;
+  ScFusedArgs* ha = (ScFusedArgs*)((uint8_t*)c->pin + 64);
+  for (size_t i = 0; i < count; i++) for (int j = 0; j < 4; j++) {
+    ha[i].src[j] = nullptr; ha[i].dst[j] = nullptr;
+    if (j >= ncols) continue;
+    sbn_table* t = cols[j][i];
+    ha[i].src[j] = (const uint32_t*)t->d;
+    if (std::find(distinct.begin(), distinct.end(), t) == distinct.end()) {
+      if (t->cap2 < len / 2) {
+        if (t->d2) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(t->d2)); t->d2 = nullptr; t->cap2 = 0; }
+        hipError_t e = hipMalloc(&t->d2, (len / 2) * 32);
+        if (e != hipSuccess) return fail(c, SBN_ENOMEM, "hipMalloc second table buffer: %s", hipGetErrorString(e));
+        t->cap2 = len / 2;
+      }
+      ha[i].dst[j] = (uint32_t*)t->d2;
+      distinct.push_back(t);
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(c->sc_args.p, ha, count * sizeof(ScFusedArgs), hipMemcpyHostToDevice, c->stream));
+  unsigned gx = stream_grid(q); if (gx > 1024) gx = 1024;
+  if ((rc = ensure(c, c->sc_partial, (size_t)count * gx * 96))) return rc;
+  if ((rc = ensure(c, c->sc_out, std::max<size_t>(4096, count * 96)))) return rc;
+  const char* nm = KIND == KIND_CUBIC ? "k_sc_bind_eval_cubic" : KIND == KIND_R1CS ? "k_sc_bind_eval_r1cs" : "k_sc_bind_eval_quad";
+  LAUNCH(c, nm, k_sc_bind_eval<KIND>, dim3(gx, (unsigned)count), 256, (const ScFusedArgs*)c->sc_args.p, q, (const uint32_t*)c->sc_r.p, (uint32_t*)c->sc_partial.p);
+  LAUNCH(c, "k_sc_finish", k_sc_finish, (unsigned)count, 64, (const uint32_t*)c->sc_partial.p, (int)gx, (uint32_t*)c->sc_out.p);
+  LAUNCHCHK(c);
+  uint8_t* hres = (uint8_t*)c->pin + 64 + count * sizeof(ScFusedArgs);
+  HIPCHK(c, hipMemcpyAsync(hres, c->sc_out.p, count * 96, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  for (sbn_table* t : distinct) { std::swap(t->d, t->d2); std::swap(t->cap, t->cap2); t->len = len / 2; }
+  if (KIND == KIND_QUAD) { for (size_t i = 0; i < count; i++) memcpy(out + 64 * i, hres + 96 * i, 64); }
+  else memcpy(out, hres, count * 96);
+  return SBN_OK;
+}
+extern "C" {
+int sbn_sc_bind_eval_cubic_batched(sbn_ctx* c, sbn_table* const* A, sbn_table* const* B, sbn_table* const* Cc, size_t count, const uint8_t r[32], uint8_t* out) {
+  if (!c || !A || !B || !Cc || !r || !out || count == 0) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  sbn_table* const* cols[3] = {A, B, Cc};
+  return sc_bind_eval_common<KIND_CUBIC>(c, cols, 3, count, r, out);
+}
+int sbn_sc_bind_eval_r1cs(sbn_ctx* c, sbn_table* T, sbn_table* A, sbn_table* B, sbn_table* Cc, const uint8_t r[32], uint8_t out[96]) {
+  if (!c || !T || !A || !B || !Cc || !r || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  sbn_table* const* cols[4] = {&T, &A, &B, &Cc};
+  return sc_bind_eval_common<KIND_R1CS>(c, cols, 4, 1, r, out);
+}
+int sbn_sc_bind_eval_quad(sbn_ctx* c, sbn_table* Z, sbn_table* ABC, const uint8_t r[32], uint8_t out[64]) {
+  if (!c || !Z || !ABC || !r || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  sbn_table* const* cols[2] = {&Z, &ABC};
+  return sc_bind_eval_common<KIND_QUAD>(c, cols, 2, 1, r, out);
 }
 int sbn_eq_evals(sbn_ctx* c, const uint8_t* r, size_t ell, sbn_table** out) {
   if (!c || (!r && ell) || !out || ell > 40) return SBN_EINVAL;

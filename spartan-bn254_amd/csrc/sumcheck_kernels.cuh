@@ -89,6 +89,65 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
   }
 }
 
+// Fused round: bind every table to r_j (hyrax.rs:195-203) AND accumulate the round-(j+1) sums from the freshly bound
+// values, in one pass: per table 4 elements are read (quarter q of the old length apart), the two bound values are
+// written to the table's second buffer and feed the next round's evaluation points directly.  One pass per round
+// instead of two: the separate eval pass (a full re-read of the bound tables) disappears.
+// dst[j] == nullptr means another instance writes that (shared) table; values are still computed for the sums.
+struct ScFusedArgs {
+  const uint32_t* src[4];
+  uint32_t* dst[4];
+};
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, size_t q /* old_len / 4 */, const uint32_t* __restrict__ rm, uint32_t* __restrict__ partial) {
+  const ScFusedArgs a = args[blockIdx.y];
+  const Fr r = fe_load<FrP>(rm);
+  constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
+  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+    Fr lo[NT], hi[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const uint32_t* z = a.src[j];
+      const Fr z0 = fe_load<FrP>(z + 8 * i), z1 = fe_load<FrP>(z + 8 * (i + q)), z2 = fe_load<FrP>(z + 8 * (i + 2 * q)), z3 = fe_load<FrP>(z + 8 * (i + 3 * q));
+      lo[j] = fe_add(z0, fe_mul(r, fe_sub(z2, z0)));
+      hi[j] = fe_add(z1, fe_mul(r, fe_sub(z3, z1)));
+      if (a.dst[j]) { fe_store<FrP>(a.dst[j] + 8 * i, lo[j]); fe_store<FrP>(a.dst[j] + 8 * (i + q), hi[j]); }
+    }
+    if (KIND == KIND_QUAD) {
+      e0 = fe_add(e0, fe_mul(lo[0], lo[1]));
+      e2 = fe_add(e2, fe_mul(fe_sub(fe_dbl(hi[0]), lo[0]), fe_sub(fe_dbl(hi[1]), lo[1])));
+    } else if (KIND == KIND_CUBIC) {
+      e0 = fe_add(e0, fe_mul(fe_mul(lo[0], lo[1]), lo[2]));
+      Fr da = fe_sub(hi[0], lo[0]), db = fe_sub(hi[1], lo[1]), dc = fe_sub(hi[2], lo[2]);
+      Fr a2 = fe_add(hi[0], da), b2 = fe_add(hi[1], db), c2 = fe_add(hi[2], dc);
+      e2 = fe_add(e2, fe_mul(fe_mul(a2, b2), c2));
+      e3 = fe_add(e3, fe_mul(fe_mul(fe_add(a2, da), fe_add(b2, db)), fe_add(c2, dc)));
+    } else {
+      e0 = fe_add(e0, fe_mul(lo[0], fe_sub(fe_mul(lo[1], lo[2]), lo[3])));
+      Fr dt = fe_sub(hi[0], lo[0]), da = fe_sub(hi[1], lo[1]), db = fe_sub(hi[2], lo[2]), dc = fe_sub(hi[3], lo[3]);
+      Fr t2 = fe_add(hi[0], dt), a2 = fe_add(hi[1], da), b2 = fe_add(hi[2], db), c2 = fe_add(hi[3], dc);
+      e2 = fe_add(e2, fe_mul(t2, fe_sub(fe_mul(a2, b2), c2)));
+      e3 = fe_add(e3, fe_mul(fe_add(t2, dt), fe_sub(fe_mul(fe_add(a2, da), fe_add(b2, db)), fe_add(c2, dc))));
+    }
+  }
+  __shared__ uint32_t sm[4][3][8];
+  e0 = wave_sum_fr(e0); e2 = wave_sum_fr(e2);
+  if (KIND != KIND_QUAD) e3 = wave_sum_fr(e3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
+    uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x);
+    for (int k = 0; k < 8; k++) o[k] = s.v[k];
+  }
+}
+
 // out[inst][3] canonical; one 64-lane block per instance folds `nblk` partial triples
 __global__ void __launch_bounds__(64) k_sc_finish(const uint32_t* __restrict__ partial, int nblk, uint32_t* __restrict__ out) {
   const int inst = blockIdx.x, lane = threadIdx.x;

@@ -76,6 +76,58 @@ def test_full_prove_cubic_loop(ctx, ol, pr):
         t.free()
 
 
+@pytest.mark.parametrize("n", [4, 8, 512, 1 << 13, 1 << 16])
+def test_fused_bind_eval_vs_oracle(ctx, ol, n):
+    """fused round == bind_top on every table, then the next round's sums (one pass instead of two)"""
+    T, A, B, C = (rand_scalars(n, s + 3 * n) for s in (1, 2, 3, 4))
+    r = rand_scalars(1, 9)
+    bT, bA, bB, bC = (ol.bind_top(x, r) for x in (T, A, B, C))
+    tT, tA, tB, tC = (ctx.table_upload(x) for x in (T, A, B, C))
+    # batched cubic with a shared C ("par" instances, sumcheck.rs:201-235) and a table used in two roles
+    got = ctx.sc_bind_eval_cubic_batched([tA, tB, tT], [tB, tT, tA], [tC, tC, tC], r)
+    assert got == ol.sc_eval_cubic(bA, bB, bC) + ol.sc_eval_cubic(bB, bT, bC) + ol.sc_eval_cubic(bT, bA, bC)
+    for t, h in ((tT, bT), (tA, bA), (tB, bB), (tC, bC)):
+        assert len(t) == n // 2 and ctx.table_download(t) == h
+    for t in (tT, tA, tB, tC):
+        t.free()
+    tT, tA, tB, tC = (ctx.table_upload(x) for x in (T, A, B, C))
+    assert ctx.sc_bind_eval_r1cs(tT, tA, tB, tC, r) == ol.sc_eval_r1cs(bT, bA, bB, bC)
+    assert ctx.table_download(tT) == bT and ctx.table_download(tC) == bC
+    for t in (tT, tA, tB, tC):
+        t.free()
+    tT, tA = ctx.table_upload(T), ctx.table_upload(A)
+    assert ctx.sc_bind_eval_quad(tT, tA, r) == ol.sc_eval_quad(bT, bA)
+    assert ctx.table_download(tA) == bA
+    # mixing with the unfused calls afterwards keeps working (buffers were swapped)
+    if n >= 8:
+        r2 = rand_scalars(1, 10)
+        ctx.bind_top_many([tT, tA], r2)
+        assert ctx.table_download(tT) == ol.bind_top(bT, r2)
+    tT.free(); tA.free()
+
+
+def test_full_prove_cubic_loop_fused(ctx, ol, pr):
+    """prove_cubic_batched driven with ONE device call per round (bind of round j fused with the sums of round j+1)"""
+    n = 1 << 11
+    A1, B1, A2, B2, C = (rand_scalars(n, s) for s in (21, 22, 23, 24, 25))
+    ts = [ctx.table_upload(x) for x in (A1, B1, A2, B2, C)]
+    tA1, tB1, tA2, tB2, tC = ts
+    hs = [A1, B1, A2, B2, C]
+    ev = ctx.sc_eval_cubic_batched([tA1, tA2], [tB1, tB2], [tC, tC])
+    rounds = 11
+    for rnd in range(rounds):
+        assert ev == ol.sc_eval_cubic(hs[0], hs[1], hs[4]) + ol.sc_eval_cubic(hs[2], hs[3], hs[4]), rnd
+        r = pr.scalar_to_bytes(int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % pr.R)
+        hs = [ol.bind_top(h, r) for h in hs]
+        if len(tA1) >= 4:
+            ev = ctx.sc_bind_eval_cubic_batched([tA1, tA2], [tB1, tB2], [tC, tC], r)
+        else:
+            ctx.bind_top_many(ts, r)          # last round: nothing left to evaluate
+    assert [ctx.table_read0(t) for t in ts] == [h[:32] for h in hs]
+    for t in ts:
+        t.free()
+
+
 @pytest.mark.parametrize("ell", [0, 1, 2, 7, 16])
 def test_eq_evals(ctx, ol, ell):
     r = rand_scalars(max(ell, 1), 3)[:32 * ell]

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Sumcheck-round throughput at keyless sizes: the batched cubic sumcheck of the ops product circuits,
+layer 0 — 12 "par" instances (A, B of 2^21) sharing one C table + 6 "seq" instances with their own C: 43 tables of
+64 MiB = 2.7 GiB touched in round 0, 21 rounds, tables halving.  Reports the whole-sumcheck time with separate
+eval + bind launches (the reference's structure) and with the fused bind+eval round, and HBM GB/s against 8 TB/s using
+ALGORITHMIC bytes: eval reads every live table once; bind reads it once and writes half; the fused round reads once and
+writes half.  Dev/measurement tool (bench.py stays the MSM metric)."""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from __graft_entry__ import load_pkg  # noqa: E402
+
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+
+
+def main():
+    logn = int(sys.argv[1]) if len(sys.argv) > 1 else 21
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    n = 1 << logn
+    sbn = load_pkg()
+    ctx = sbn.Context(0)
+    dev = torch.device("cuda:0")
+    NPAR, NSEQ = 12, 6
+    ntab = 2 * NPAR + 1 + 3 * NSEQ
+
+    def fresh():
+        g = torch.Generator(device=dev); g.manual_seed(7)
+        ts = []
+        for _ in range(ntab):
+            x = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int32, device=dev, generator=g); x[:, 7] &= 0x0fffffff
+            torch.cuda.synchronize()
+            ts.append(ctx.table_from_dev(x.data_ptr(), n, sbn.SBN_SCALARS_MONT)); del x
+        par_a, par_b, c_par = ts[:NPAR], ts[NPAR:2 * NPAR], ts[2 * NPAR]
+        rest = ts[2 * NPAR + 1:]
+        seq_a, seq_b, seq_c = rest[:NSEQ], rest[NSEQ:2 * NSEQ], rest[2 * NSEQ:]
+        As, Bs, Cs = par_a + seq_a, par_b + seq_b, [c_par] * NPAR + seq_c
+        return ts, As, Bs, Cs
+
+    def challenge(ev):
+        return (int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % R_MOD).to_bytes(32, "little")
+
+    res = {}
+    for mode in ("separate", "fused"):
+        times = []
+        for rep in range(reps + 1):
+            ts, As, Bs, Cs = fresh()
+            ctx.prof_enable(True); ctx.prof_reset()
+            ctx.sync(); t0 = time.perf_counter()
+            ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+            for rnd in range(logn):
+                r = challenge(ev)
+                if mode == "fused" and len(ts[0]) >= 4:
+                    ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+                else:
+                    ctx.bind_top_many(ts, r)
+                    if len(ts[0]) >= 2:
+                        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+            ctx.sync(); dt = time.perf_counter() - t0
+            prof = ctx.prof_get(); ctx.prof_enable(False)
+            finals = [ctx.table_read0(t) for t in ts[:3]]
+            for t in ts:
+                t.free()
+            if rep:
+                times.append(dt)
+        res[mode] = {"ms_per_sumcheck": round(1e3 * sum(times) / len(times), 3), "finals": [f.hex()[:16] for f in finals],
+                     "kernels_ms_total": {k: round(v[0], 3) for k, v in prof.items()}, "kernels_launches": {k: v[1] for k, v in prof.items()}}
+    assert res["separate"]["finals"] == res["fused"]["finals"], "fused and separate rounds disagree"
+    table_bytes = ntab * n * 32
+    # sum over rounds of live bytes: 2 * table_bytes (geometric)
+    alg_sep = 2 * table_bytes * (1 + 1 + 0.5)          # eval read + bind read + bind write
+    alg_fused = table_bytes + 2 * table_bytes * (1 + 0.5) - table_bytes * 0  # first eval + fused rounds (read + half write) over all rounds
+    for mode, alg in (("separate", alg_sep), ("fused", alg_fused)):
+        ms = res[mode]["ms_per_sumcheck"]
+        res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
+        res[mode]["GBps_vs_8000"] = round(alg / (ms * 1e-3) / 1e9, 1)
+    print(json.dumps({"workload": f"batched cubic sumcheck, {NPAR} par + {NSEQ} seq instances, tables of 2^{logn}, {logn} rounds, {round(table_bytes / 2**30, 2)} GiB in round 0", **res}))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
