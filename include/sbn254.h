@@ -59,6 +59,11 @@ int sbn_dev_download(sbn_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 int sbn_msm(sbn_ctx* ctx, const uint8_t* scalars, const uint8_t* points, size_t n, uint32_t flags,
             uint8_t out_xy[64], int* out_is_inf);
 
+/* vartime_multiscalar_mul (group.rs:143-158) takes PROJECTIVE points and converts each with its own inversion on the CPU
+ * (group.rs:153); here the n Jacobian triples X||Y||Z (96 B each; Z = 0 is the identity) are normalised on the device. */
+int sbn_msm_jacobian(sbn_ctx* ctx, const uint8_t* scalars, const uint8_t* points_xyz, size_t n, uint32_t flags,
+                     uint8_t out_xy[64], int* out_is_inf);
+
 /* ---- generator tables — MultiCommitGens (commitments.rs:17-27).  G: n points, h: 1 point or NULL.
  *      Stored on the device in Montgomery form; duplicates are detected so that commit() can merge the
  *      scalars of equal bases (the reference's derivation makes ~66 % of them equal to G, group.rs:110-131). ---- */
@@ -74,6 +79,11 @@ int sbn_gens_new(sbn_ctx* ctx, size_t n, const uint8_t* label, size_t label_len,
 int sbn_bases_synthetic(sbn_ctx* ctx, size_t n, uint64_t first, const uint8_t s0[32], const uint8_t d[32], sbn_bases** out);
 /* copy `count` points starting at `first` back to the host as canonical x||y (for tests of resident tables) */
 int sbn_bases_download(sbn_ctx* ctx, const sbn_bases* b, size_t first, size_t count, uint8_t* out_xy);
+
+/* MultiCommitGens::split_at(mid) (commitments.rs:78-98): (G[..mid], h) and (G[mid..], h) */
+int sbn_bases_split_at(sbn_ctx* ctx, const sbn_bases* b, size_t mid, sbn_bases** left, sbn_bases** right);
+/* MultiCommitGens::scale(s) (commitments.rs:64-76): G_i <- s * G_i, h unchanged */
+int sbn_bases_scale(sbn_ctx* ctx, const sbn_bases* b, const uint8_t s[32], sbn_bases** out);
 
 /* MSM of n scalars against the first n points of a resident table (no h): msm_affine with cached G_affine */
 int sbn_msm_bases(sbn_ctx* ctx, const sbn_bases* b, const uint8_t* scalars, size_t n, uint32_t flags,

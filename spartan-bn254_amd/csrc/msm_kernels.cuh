@@ -550,6 +550,32 @@ __global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z
   if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * U + u), acc);
 }
 
+// Jacobian (X, Y, Z) -> Montgomery affine, one lane per point (x = X/Z^2, y = Y/Z^3); canonical input is converted first
+__global__ void __launch_bounds__(64) k_jacobian_to_affine(const uint32_t* __restrict__ in, int in_is_mont, size_t n, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fq X = fe_load<FqP>(in + 24 * i), Y = fe_load<FqP>(in + 24 * i + 8), Z = fe_load<FqP>(in + 24 * i + 16);
+  if (!in_is_mont) { X = fe_to_mont(X); Y = fe_to_mont(Y); Z = fe_to_mont(Z); }
+  Affine a;
+  if (fe_is_zero(Z)) { a.x = fe_zero<FqP>(); a.y = a.x; }
+  else { const Fq zi = fe_inv(Z), zi2 = fe_sqr(zi); a.x = fe_mul(X, zi2); a.y = fe_mul(Y, fe_mul(zi2, zi)); }
+  aff_store(out + 16 * i, a);
+}
+// s * P_i for every point of a table (MultiCommitGens::scale): double-and-add, scalar shared by all lanes
+__global__ void __launch_bounds__(64) k_scale_points(const uint32_t* __restrict__ pts, size_t n, const uint32_t* __restrict__ scalar /* canonical */, uint32_t* __restrict__ out_xyzz) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Affine P = aff_load(pts + 16 * i);
+  XYZZ acc = xyzz_inf();
+  int top = 255;
+  while (top >= 0 && !((scalar[top >> 5] >> (top & 31)) & 1u)) top--;
+  for (int b = top; b >= 0; b--) {
+    acc = xyzz_dbl(acc);
+    if ((scalar[b >> 5] >> (b & 31)) & 1u) xyzz_madd(acc, P, false);
+  }
+  xyzz_store(out_xyzz + 32 * i, acc);
+}
+
 // P_i = P0 + (first + i) * D : lane-local double-and-add on the 64-bit index (synthetic bases with known dlogs)
 __global__ void __launch_bounds__(64) k_arith_points(const uint32_t* __restrict__ p0d /* P0, D as XYZZ */, unsigned long long first, size_t n, uint32_t* __restrict__ out_xyzz) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

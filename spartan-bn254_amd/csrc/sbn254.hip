@@ -606,6 +606,63 @@ int sbn_gens_new(sbn_ctx* c, size_t n, const uint8_t* label, size_t label_len, u
   return SBN_OK;
 }
 
+int sbn_msm_jacobian(sbn_ctx* c, const uint8_t* scalars, const uint8_t* points_xyz, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf) {
+  if (!c || !out_xy || ((!scalars || !points_xyz) && n)) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  int rc; const uint32_t* ds;
+  if ((rc = stage_scalars(c, scalars, n, flags, &ds))) return rc;
+  if ((rc = ensure(c, c->gen_tmp, n * 96))) return rc;
+  if ((rc = ensure(c, c->stage_pts, n * 64))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->gen_tmp.p, points_xyz, n * 96, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "k_jacobian_to_affine", k_jacobian_to_affine, (unsigned)((n + 63) / 64), 64, (const uint32_t*)c->gen_tmp.p, (flags & SBN_POINTS_MONT) ? 1 : 0, n, (uint32_t*)c->stage_pts.p);
+  return msm_device(c, ds, (const uint32_t*)c->stage_pts.p, n, out_xy, out_is_inf);
+}
+// device-side copy of a point range into a new handle (keys for the duplicate detection are read back once)
+static int bases_from_device(sbn_ctx* c, const void* d_G, size_t n, const void* d_h, sbn_bases** out) {
+  const size_t tot = n + (d_h ? 1 : 0);
+  sbn_bases* b = new sbn_bases(); b->n = n; b->has_h = d_h != nullptr;
+  hipError_t e = hipMalloc(&b->d_pts, (tot ? tot : 1) * 64);
+  if (e != hipSuccess) { delete b; return fail(c, SBN_ENOMEM, "hipMalloc bases: %s", hipGetErrorString(e)); }
+  if (n) HIPCHK(c, hipMemcpyAsync(b->d_pts, d_G, n * 64, hipMemcpyDeviceToDevice, c->stream));
+  if (d_h) HIPCHK(c, hipMemcpyAsync((uint8_t*)b->d_pts + n * 64, d_h, 64, hipMemcpyDeviceToDevice, c->stream));
+  std::vector<std::string> keys(tot);
+  std::vector<uint8_t> host(tot * 64);
+  if (tot) HIPCHK(c, hipMemcpyAsync(host.data(), b->d_pts, tot * 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t j = 0; j < tot; j++) keys[j].assign((const char*)&host[64 * j], 64);
+  int rc = bases_build_dedupe(c, b, keys);
+  if (rc) { sbn_bases_free(c, b); return rc; }
+  *out = b;
+  return SBN_OK;
+}
+int sbn_bases_split_at(sbn_ctx* c, const sbn_bases* b, size_t mid, sbn_bases** left, sbn_bases** right) {
+  if (!c || !b || !left || !right || mid > b->n) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  const uint8_t* p = (const uint8_t*)b->d_pts; const void* h = b->has_h ? p + 64 * b->n : nullptr;
+  int rc;
+  if ((rc = bases_from_device(c, p, mid, h, left))) return rc;
+  if ((rc = bases_from_device(c, p + 64 * mid, b->n - mid, h, right))) { sbn_bases_free(c, *left); *left = nullptr; return rc; }
+  return SBN_OK;
+}
+int sbn_bases_scale(sbn_ctx* c, const sbn_bases* b, const uint8_t s[32], sbn_bases** out) {
+  if (!c || !b || !s || !out) return SBN_EINVAL;
+  if (!fr_canonical(s)) return fail(c, SBN_EINVAL, "scale: scalar not canonical");
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  int rc; const size_t n = b->n;
+  if ((rc = ensure(c, c->gen_tmp, 64 + n * 128 + n * 64))) return rc;
+  uint8_t* d_s = (uint8_t*)c->gen_tmp.p; uint8_t* d_x = d_s + 64; uint8_t* d_a = d_x + n * 128;
+  HIPCHK(c, hipMemcpyAsync(d_s, s, 32, hipMemcpyHostToDevice, c->stream));
+  if (n) {
+    LAUNCH(c, "k_scale_points", k_scale_points, (unsigned)((n + 63) / 64), 64, (const uint32_t*)b->d_pts, n, (const uint32_t*)d_s, (uint32_t*)d_x);
+    LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((n + 63) / 64), 64, (const uint32_t*)d_x, (uint32_t*)d_a, (uint32_t*)nullptr, (uint8_t*)nullptr, n);
+  }
+  LAUNCHCHK(c);
+  return bases_from_device(c, d_a, n, b->has_h ? (const uint8_t*)b->d_pts + 64 * n : nullptr, out);
+}
 int sbn_bases_synthetic(sbn_ctx* c, size_t n, uint64_t first, const uint8_t s0[32], const uint8_t d[32], sbn_bases** out) {
   if (!c || !out || !s0 || !d || n == 0) return SBN_EINVAL;
   if (!fr_canonical(s0) || !fr_canonical(d)) return fail(c, SBN_EINVAL, "synthetic bases: s0/d not canonical");

@@ -90,6 +90,42 @@ def test_resident_bases_and_prefix(ctx, ol, pr):
         b.free()
 
 
+def test_msm_jacobian_points(ctx, ol, pr):
+    """vartime_multiscalar_mul (group.rs:143-158): projective inputs, including Z != 1 representatives and the identity"""
+    n = 200
+    sc = rand_scalars(n, 31); pts, dl = tiled_bases(ol, n, n, 32)
+    zs = rand_scalars(n, 33)
+    xyz = bytearray()
+    for i in range(n):
+        x, y = (int.from_bytes(pts[64 * i + 32 * j:64 * i + 32 * j + 32], "little") for j in (0, 1))
+        z = int.from_bytes(zs[32 * i:32 * i + 32], "little") % pr.P or 1
+        if i == 7:
+            xyz += (1).to_bytes(32, "little") + (1).to_bytes(32, "little") + bytes(32)     # identity: Z = 0
+            continue
+        xyz += (x * z * z % pr.P).to_bytes(32, "little") + (y * z * z * z % pr.P).to_bytes(32, "little") + z.to_bytes(32, "little")
+    dl7 = bytearray(dl); dl7[32 * 7:32 * 8] = bytes(32)                                    # point 7 contributes nothing
+    out, inf = ctx.msm_jacobian(sc, bytes(xyz))
+    assert out == expect_from_dlogs(ol, pr, sc, bytes(dl7)) and not inf
+
+
+def test_bases_split_and_scale(ctx, ol, pr):
+    """MultiCommitGens::split_at / scale (commitments.rs:64-98), as DotProductProofGens::new uses them (nizk/mod.rs:412-415)"""
+    n = 40
+    b, gxy = ctx.gens_new(n, b"gens_r1cs_sat")
+    left, right = ctx.bases_split_at(b, 25)
+    assert len(left) == 25 and len(right) == 15
+    assert ctx.bases_download(left, 0, 26) == gxy[:64 * 25] + gxy[64 * n:]                # G[..mid] + h
+    assert ctx.bases_download(right, 0, 16) == gxy[64 * 25:]                                # G[mid..] + h
+    sc = rand_scalars(15, 1); bl = rand_scalars(1, 2)
+    assert ctx.commit_rows(right, sc, bl, 1, 15)[0] == ol.commit(sc, bl, gxy[64 * 25:64 * n], gxy[64 * n:])
+    s = rand_scalars(1, 3)
+    scaled = ctx.bases_scale(b, s)
+    want = b"".join(ol.g1_mul(gxy[64 * i:64 * i + 64], s) for i in range(n)) + gxy[64 * n:]   # h unchanged
+    assert ctx.bases_download(scaled, 0, n + 1) == want
+    for x in (left, right, scaled, b):
+        x.free()
+
+
 def test_gens_new_matches_golden_and_oracle(ctx, ol):
     g = golden("gens_kat.json")
     for label, row in g.items():
