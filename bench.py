@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="msm: log2 of the points per GPU")
     ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows per GPU")
     ap.add_argument("--cols", type=int, default=8192, help="hyrax: matrix columns")
-    ap.add_argument("--inflight", type=int, default=2, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
+    ap.add_argument("--inflight", type=int, default=4, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
     ap.add_argument("--fixed-base", action="store_true", help="msm: treat the resident bases as fixed generators (per-window multiples precomputed once, "
                     "as the commit path does): sbn_commit_rows with L = 1 instead of sbn_msm_bases")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,6 +251,18 @@ def main():
         for k, (ms, cnt) in cx.prof_get().items():
             a, b = prof.get(k, (0.0, 0)); prof[k] = (a + ms, b + cnt)
         cx.prof_enable(False)
+    # serial reference: a few steps one at a time on one stream — the latency of a single call and per-kernel durations that
+    # are not stretched by other streams' kernels running beside them
+    serial = None
+    if M > 1:
+        ns_ser = max(2, min(8, args.steps))
+        ctx.prof_enable(True); ctx.prof_reset()
+        barrier(); ts0 = time.perf_counter()
+        for _ in range(ns_ser):
+            step()
+        barrier(); ts = time.perf_counter() - ts0
+        sp = ctx.prof_get(); ctx.prof_enable(False)
+        serial = {"steps": ns_ser, "ms_per_step": round(ts / ns_ser * 1e3, 4), "kernels_avg_ms": {k: round(ms / max(cnt, 1), 4) for k, (ms, cnt) in sp.items()}}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -273,6 +285,10 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
                     "kernel_avg_ms": round(dom_avg_ms, 4),
                     "note": "MSM is integer-ALU bound (~170 modular products per point vs 96 B): see DESIGN.md for the ALU roofline"}
+        if serial and serial["kernels_avg_ms"].get(dominant):
+            sa = alg_bytes_per_launch / (serial["kernels_avg_ms"][dominant] * 1e-3) / 1e9
+            roofline["serial_pass"] = {"kernel_avg_ms": serial["kernels_avg_ms"][dominant], "achieved": round(sa, 2), "frac": round(sa / HBM_PEAK_GBS, 5),
+                                       "note": "same kernel with ONE step in flight: with several streams a launch shares the chip, so its event-to-event time is longer"}
         if not args.no_cpu_baseline and world == 1:
             cores = min(len(os.sched_getaffinity(0)), 16)
             if args.workload == "msm":
@@ -297,7 +313,7 @@ def main():
                 "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "steps_in_flight": M, "collective_backend": backend if world > 1 else None,
                            "sharding": "base-point ranges + one RCCL all-gather of 64-B partial sums" if args.workload == "msm" else "independent matrices per GPU, no collective",
                            "parity": "bit-exact vs discrete-log oracle, checked before timing"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kern}
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kern, "serial_reference": serial}
         print(json.dumps(line), flush=True)
     bases.free()
     pool.shutdown()
