@@ -142,6 +142,20 @@ int sbn_sc_bind_eval_quad(sbn_ctx* ctx, sbn_table* Z, sbn_table* ABC, const uint
 /* EqPolynomial::evals (hyrax.rs:355-369) built on the device */
 int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
 
+/* ---- derefs on the device ----
+ * MultiSparseMatPolynomialAsDense::deref -> AddrTimestamps::deref_mem (sparse_mlpoly_full.rs:245-257, 275-279) followed by
+ * Derefs::new -> DensePolynomial::merge (sparse_mlpoly_full.rs:293-297, hyrax.rs:237-247):
+ *   out = concat_k [ mem[k][addr[k][i]] for i < n ], zero-padded to the next power of two.
+ * mem[k]: the table instance k reads (the eq(rx) table for the row_ops_val polys, eq(ry) for col_ops_val: build them with
+ * sbn_eq_evals).  addr[k]: DEVICE arrays of n uint32 cell indices (fixed per circuit: upload once with sbn_dev_upload).
+ * The result is a table (the `comb` polynomial), ready for sbn_commit_table — the 1 GiB scalar matrix of the keyless
+ * derefs commitment never crosses PCIe. */
+int sbn_gather_merge(sbn_ctx* ctx, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n, sbn_table** out);
+/* DensePolynomial::commit (hyrax.rs:283-308) of a device-resident table viewed as L x R (L*R == len, R == gens n); blinds as
+ * in sbn_commit_rows (host pointer or NULL) */
+int sbn_commit_table(sbn_ctx* ctx, const sbn_bases* b, const sbn_table* t, const uint8_t* blinds, size_t L, size_t R,
+                     uint8_t* out_xy, uint8_t* out_inf);
+
 /* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline line ---- */
 int sbn_prof_enable(sbn_ctx* ctx, int on);
 int sbn_prof_reset(sbn_ctx* ctx);

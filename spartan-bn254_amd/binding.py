@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
 
@@ -289,6 +289,18 @@ class Context:
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()
         self._chk(lib().sbn_eq_evals(self.h, _ptr(r), C.c_size_t(ell), C.byref(ht)), "sbn_eq_evals"); return Table(self, ht)
+
+    def gather_merge(self, mems, addr_dev_ptrs, n):
+        k = len(mems)
+        ma = (C.c_void_p * k)(*[t.h for t in mems]); aa = (C.c_void_p * k)(*addr_dev_ptrs)
+        ht = C.c_void_p()
+        self._chk(lib().sbn_gather_merge(self.h, ma, aa, C.c_size_t(k), C.c_size_t(n), C.byref(ht)), "sbn_gather_merge")
+        return Table(self, ht)
+
+    def commit_table(self, bases, t, blinds, L, R):
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_commit_table(self.h, bases.h, t.h, _ptr(blinds), C.c_size_t(L), C.c_size_t(R), out, inf), "sbn_commit_table")
+        return bytes(out), bytes(inf)
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -906,6 +906,48 @@ int sbn_sc_bind_eval_quad(sbn_ctx* c, sbn_table* Z, sbn_table* ABC, const uint8_
   sbn_table* const* cols[2] = {&Z, &ABC};
   return sc_bind_eval_common<KIND_QUAD>(c, cols, 2, 1, r, out);
 }
+int sbn_gather_merge(sbn_ctx* c, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n, sbn_table** out) {
+  if (!c || !mem || !addr_dev || !out || count == 0 || n == 0) return SBN_EINVAL;
+  for (size_t k = 0; k < count; k++) if (!mem[k] || !addr_dev[k]) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  size_t padded = 1; while (padded < count * n) padded <<= 1;              // Z.resize(len.next_power_of_two()) (hyrax.rs:245)
+  int rc;
+  if ((rc = ensure(c, c->sc_args, count * sizeof(GatherArgs) + 64))) return rc;
+  if ((rc = ensure_pin(c, 4096 + count * sizeof(GatherArgs)))) return rc;
+  GatherArgs* ha = (GatherArgs*)((uint8_t*)c->pin + 64);
+  for (size_t k = 0; k < count; k++) { ha[k].mem = (const uint32_t*)mem[k]->d; ha[k].addr = (const uint32_t*)addr_dev[k]; ha[k].mem_len = mem[k]->len; }
+  uint8_t* d_args = (uint8_t*)c->sc_args.p; uint32_t* d_oob = (uint32_t*)(d_args + count * sizeof(GatherArgs));
+  HIPCHK(c, hipMemcpyAsync(d_args, ha, count * sizeof(GatherArgs), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(d_oob, 0, 4, c->stream));
+  sbn_table* t = new sbn_table(); t->len = padded; t->cap = padded;
+  hipError_t e = hipMalloc(&t->d, padded * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc gather table: %s", hipGetErrorString(e)); }
+  LAUNCH(c, "k_gather_merge", k_gather_merge, stream_grid(padded), 256, (const GatherArgs*)d_args, count, n, padded, (uint32_t*)t->d, d_oob);
+  LAUNCHCHK(c);
+  uint32_t oob = 0;
+  HIPCHK(c, hipMemcpyAsync(c->pin, d_oob, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  memcpy(&oob, c->pin, 4);
+  if (oob) { hipFree(t->d); delete t; return fail(c, SBN_EINVAL, "gather: %u addresses are outside their memory table (sparse_mlpoly_full.rs:228 assert)", oob); }
+  *out = t;
+  return SBN_OK;
+}
+int sbn_commit_table(sbn_ctx* c, const sbn_bases* b, const sbn_table* t, const uint8_t* blinds, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+  if (!c || !b || !t || (!out_xy && L)) return SBN_EINVAL;
+  if (L * R != t->len) return fail(c, SBN_EINVAL, "commit_table: L*R (%zu) != table length (%zu)  [hyrax.rs:257 assert_eq]", L * R, t->len);
+  void* dB = nullptr; int rc;
+  if (blinds) {
+    if ((rc = sbn_dev_alloc(c, L * 32, &dB))) return rc;
+    if ((rc = sbn_dev_upload(c, dB, blinds, L * 32))) { sbn_dev_free(c, dB); return rc; }
+    // blinds arrive canonical while the table is Montgomery: bring the blinds to Montgomery form so one flag covers both
+    std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+    LAUNCH(c, "k_fr_to_mont", k_fr_to_mont, stream_grid(L), 256, (const uint32_t*)dB, (uint32_t*)dB, L);
+  }
+  rc = sbn_commit_rows_dev(c, b, t->d, dB, L, R, SBN_SCALARS_MONT, out_xy, out_inf);
+  if (dB) sbn_dev_free(c, dB);
+  return rc;
+}
 int sbn_eq_evals(sbn_ctx* c, const uint8_t* r, size_t ell, sbn_table** out) {
   if (!c || (!r && ell) || !out || ell > 40) return SBN_EINVAL;
   std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);

@@ -188,6 +188,20 @@ __global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ i
     fe_store<FrP>(out + 8 * (2 * k), fe_sub(s, hi));
   }
 }
+// out[k*n + i] = mem[k][addr[k][i]]  (AddrTimestamps::deref_mem, sparse_mlpoly_full.rs:245-252), zero padding past count*n
+struct GatherArgs { const uint32_t* mem; const uint32_t* addr; size_t mem_len; };
+__global__ void __launch_bounds__(256) k_gather_merge(const GatherArgs* __restrict__ args, size_t count, size_t n, size_t padded, uint32_t* __restrict__ out, uint32_t* __restrict__ oob) {
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += (size_t)gridDim.x * blockDim.x) {
+    Fr v = fe_zero<FrP>();
+    if (t < count * n) {
+      const size_t k = t / n, i = t - k * n;
+      const GatherArgs a = args[k];
+      const uint32_t idx = a.addr[i];
+      if (idx < a.mem_len) v = fe_load<FrP>(a.mem + 8 * (size_t)idx); else atomicAdd(oob, 1u);   // sparse_mlpoly_full.rs:228 assert!(addr < num_cells)
+    }
+    fe_store<FrP>(out + 8 * t, v);
+  }
+}
 __global__ void k_fr_set_one(uint32_t* out) { if (threadIdx.x == 0 && blockIdx.x == 0) fe_store<FrP>(out, fe_one<FrP>()); }
 
 }  // namespace sbn

@@ -195,3 +195,40 @@ def test_full_size_round_properties(ctx, ol, pr):
         assert got[32 * lo:32 * (lo + 512)] == ol.bind_top(small, r)
     for t in full + first + second:
         t.free()
+
+
+def test_derefs_gather_and_commit(ctx, ol, pr, sbn):
+    """SURVEY 8f-1: MultiSparseMatPolynomialAsDense::deref + Derefs::new + Derefs::commit entirely on the device:
+    eq tables (hyrax.rs:355-369) -> gather by address (sparse_mlpoly_full.rs:245-257) -> merge with zero padding
+    (hyrax.rs:237-247) -> Hyrax commit (hyrax.rs:283-308).  Small instance of the keyless structure: 3 + 3 polys."""
+    import numpy as np
+    ell, nops = 6, 40                                    # 64 memory cells, 40 ops per matrix (padded total 6*40 -> 256)
+    rx, ry = rand_scalars(ell, 1), rand_scalars(ell, 2)
+    mem_rx, mem_ry = ctx.eq_evals(rx), ctx.eq_evals(ry)
+    hrx, hry = ol.eq_evals(rx), ol.eq_evals(ry)
+    rng = np.random.default_rng(5)
+    addrs = [rng.integers(0, 1 << ell, size=nops, dtype=np.uint32) for _ in range(6)]
+    addrs[1][10:] = 0                                    # padded ops read cell 0 (sparse_mlpoly_full.rs:89-101)
+    dptrs = []
+    for a in addrs:
+        p = ctx.dev_alloc(a.nbytes); ctx.dev_upload(p, a.tobytes()); dptrs.append(p)
+    comb = ctx.gather_merge([mem_rx] * 3 + [mem_ry] * 3, dptrs, nops)
+    want = b"".join(b"".join((hrx if k < 3 else hry)[32 * int(i):32 * int(i) + 32] for i in addrs[k]) for k in range(6))
+    want += bytes(32 * (256 - 6 * nops))
+    assert len(comb) == 256 and ctx.table_download(comb) == want
+    # commit the comb polynomial: ell = 8 -> L = 16 rows, R = 16 columns (hyrax.rs:371-373)
+    L, R = 1 << sbn.factored_lens(8)[0], 1 << sbn.factored_lens(8)[1]
+    bases, gxy = ctx.gens_new(R, b"gens_r1cs_eval")
+    out, infs = ctx.commit_table(bases, comb, None, L, R)
+    assert out == ol.commit_rows(want, None, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    bl = rand_scalars(L, 9)
+    assert ctx.commit_table(bases, comb, bl, L, R)[0] == ol.commit_rows(want, bl, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    # an address outside its table is rejected (sparse_mlpoly_full.rs:228 assert)
+    bad = np.full(nops, 1 << ell, dtype=np.uint32); pb = ctx.dev_alloc(bad.nbytes); ctx.dev_upload(pb, bad.tobytes())
+    with pytest.raises(sbn.SbnError):
+        ctx.gather_merge([mem_rx], [pb], nops)
+    for p in dptrs + [pb]:
+        ctx.dev_free(p)
+    for t in (comb, mem_rx, mem_ry):
+        t.free()
+    bases.free()
