@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""The reference's three prover stages around the hot path, at keyless size, entirely on the device:
+   EqPolynomial evaluation (0.10 s), Derefs computation (0.14 s), Derefs commitment (166.2 s)   [BENCHMARK_RESULTS.md:37-39]
+   = sparse_mlpoly_full.rs:1713-1727: 2 x eq table of 2^21, gather 6 x 2^22 -> comb of 2^25 (zero padded), Hyrax commit
+   4096 x 8192 over gens_derefs, compressed points for the transcript.
+Only rx, ry (21 scalars each) go host -> device and 4096 x 64 B come back.  Synthetic addresses (the keyless R1CS is not
+available offline): uniform cells < 2^20 for the first ~75 % of each matrix, cell 0 for the padded tail."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from __graft_entry__ import load_pkg  # noqa: E402
+from conftest import rand_scalars  # noqa: E402
+
+
+def main():
+    sbn = load_pkg()
+    ctx = sbn.Context(0)
+    dev = torch.device("cuda:0")
+    ell_mem, nops, L, R = 21, 1 << 22, 4096, 8192
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    addrs = []
+    for k in range(6):
+        a = torch.randint(0, 1 << 20, (nops,), dtype=torch.int32, device=dev, generator=g)
+        a[int(nops * 0.75):] = 0
+        addrs.append(a)
+    torch.cuda.synchronize()
+    bases, _ = ctx.gens_new(R, b"gens_r1cs_eval", want_points=False)
+    rx, ry = rand_scalars(ell_mem, 1), rand_scalars(ell_mem, 2)
+    times = []
+    for rep in range(4):
+        ctx.prof_enable(True); ctx.prof_reset()
+        ctx.sync(); t0 = time.perf_counter()
+        mem_rx, mem_ry = ctx.eq_evals(rx), ctx.eq_evals(ry)
+        t1 = time.perf_counter()
+        comb = ctx.gather_merge([mem_rx] * 3 + [mem_ry] * 3, [a.data_ptr() for a in addrs], nops)
+        t2 = time.perf_counter()
+        out, infs = ctx.commit_table(bases, comb, None, L, R)
+        comp = sbn.g1_compress(out)
+        t3 = time.perf_counter()
+        prof = ctx.prof_get(); ctx.prof_enable(False)
+        for t in (mem_rx, mem_ry, comb):
+            t.free()
+        if rep:
+            times.append((t1 - t0, t2 - t1, t3 - t2))
+    eq_ms, ga_ms, co_ms = (1e3 * sum(x[i] for x in times) / len(times) for i in range(3))
+    assert all(infs[i] == 1 for i in range(3072, 4096)) and len(comp) == 32 * L
+    print(json.dumps({"stage_ms": {"eq_evals_2x2^21": round(eq_ms, 3), "derefs_gather_6x2^22_to_2^25": round(ga_ms, 3), "derefs_commit_4096x8192_incl_compress": round(co_ms, 3),
+                                   "total": round(eq_ms + ga_ms + co_ms, 3)},
+                      "reference_published_s_M2Max_1thread": {"eq": 0.10, "derefs": 0.14, "commit": 166.2},
+                      "kernels_ms": {k: round(v[0] / max(v[1], 1), 3) for k, v in prof.items()}}))
+    bases.free(); ctx.close()
+
+
+if __name__ == "__main__":
+    main()
