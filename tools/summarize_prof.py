@@ -29,16 +29,17 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
-    stats = glob.glob(os.path.join(prof_dir, "trace", "**", "*_kernel_stats.csv"), recursive=True)
-    if stats:
+    for sub, suffix in (("trace", ""), ("trace_serial", "_serial")):
+      stats = glob.glob(os.path.join(prof_dir, sub, "**", "*_kernel_stats.csv"), recursive=True)
+      if stats:
         rows = list(csv.DictReader(open(stats[0])))
-        with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w", newline="") as f:
+        with open(os.path.join(out_dir, f"{tag}{suffix}_kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
             for r in rows:
                 w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs']) / 1e6:.4f}", f"{float(r['AverageNs']) / 1e6:.4f}", r["Percentage"],
                             f"{float(r['MinNs']) / 1e6:.4f}", f"{float(r['MaxNs']) / 1e6:.4f}"])
-        print("wrote", f"profiles/{tag}_kernel_stats.csv")
+        print("wrote", f"profiles/{tag}{suffix}_kernel_stats.csv")
     sums = defaultdict(lambda: defaultdict(float)); cnts = defaultdict(lambda: defaultdict(int))
     for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         for path in glob.glob(os.path.join(prof_dir, sub, "**", "*_counter_collection.csv"), recursive=True):
