@@ -183,7 +183,12 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
   if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
   if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
-  int L = s.nb / 64; if (L > 4) L = 4; if (L < 1) L = 1;
+  // buckets per lane in the reduction: few buckets -> short lane chains and more waves (latency-bound regime); many buckets ->
+  // longer chains amortise the wave-level scan/tree (throughput-bound regime).  Aim for ~2048 waves.
+  int L = 1; while ((size_t)L * 64 * 2048 < NB && L < 16) L <<= 1;
+  if (L < 4) L = 4;
+  if (L > s.nb / 64) L = s.nb / 64;
+  if (L < 1) L = 1;
   if (const char* el = getenv("SBN_RED_L")) { int v = atoi(el); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= s.nb / 64) L = v; }
   int logL = 0; while ((1 << logL) < L) logL++;
   const int chunks = s.nb / (64 * L);                     // per problem, >= 1
