@@ -41,6 +41,9 @@ struct sbn_ctx {
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, pts_mont, hist, offs, cursor, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
   DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
+  hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
+  hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
+  DevBuf zstage[2], out_rows;
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
@@ -215,6 +218,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
   if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
   else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
+  if (c->z_consumed && J.mode == MODE_ROWS) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));   // the scalars are not read again
   const size_t rows_lds = sort_rows_lds_bytes(s.nb);
   if (J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT")) {
     ProfScope _ps(c, "k_sort_rows");
@@ -298,7 +302,8 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
 }
 
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
-static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+// launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
+static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf) {
   if (L == 0) return SBN_OK;
   if (b->uniq) {
     // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
@@ -307,10 +312,11 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     uint32_t* m = (uint32_t*)c->merged.p;
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * U + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, m);
     if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, m);
-    return commit_rows_device(c, b->uniq, m, nullptr, L, U, out_xy, out_inf);
+    if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
+    return commit_rows_launch(c, b->uniq, m, nullptr, L, U, d_xy, d_inf);
   }
   const size_t ncol = R + (dBl ? 1 : 0);
-  if (ncol == 0) { memset(out_xy, 0, 64 * L); if (out_inf) memset(out_inf, 1, L); return SBN_OK; }
+  if (ncol == 0) { HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK; }
   BucketJob J; memset(&J, 0, sizeof J);
   J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16); J.P = L; J.threads = L * ncol;
   const size_t npts = b->n + (b->has_h ? 1 : 0);
@@ -320,11 +326,17 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   J.points = tab;
   J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
   if ((rc = run_bucket_job(c, J))) return rc;
-  if ((rc = ensure(c, c->out_small, L * 65))) return rc;
-  if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
-  uint32_t* d_xy = (uint32_t*)c->out_small.p; uint8_t* d_inf = (uint8_t*)c->out_small.p + L * 64;
   LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
   LAUNCHCHK(c);
+  return SBN_OK;
+}
+// Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
+static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+  if (L == 0) return SBN_OK;
+  int rc;
+  if ((rc = ensure(c, c->out_small, L * 65))) return rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
+  if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->pin, c->out_small.p, L * 65, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof) prof_drain(c);
@@ -420,10 +432,11 @@ void sbn_ctx_destroy(sbn_ctx* c) {
   hipStreamSynchronize(c->stream);
   prof_drain(c);
   DevBuf* bufs[] = {&c->scal_canon, &c->pts_mont, &c->hist, &c->offs, &c->cursor, &c->sorted, &c->buckets, &c->red_a, &c->red_b, &c->wsum, &c->stage_scal, &c->stage_pts, &c->out_small,
-                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list, &c->digits, &c->blockhist, &c->size_bins, &c->perm, &c->merged};
+                    &c->sc_args, &c->sc_partial, &c->sc_out, &c->sc_r, &c->sc_tabs, &c->gen_tmp, &c->acc_ctr, &c->extra_list, &c->extra_out, &c->big_list, &c->digits, &c->blockhist, &c->size_bins, &c->perm, &c->merged, &c->zstage[0], &c->zstage[1], &c->out_rows};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (c->pin) hipHostFree(c->pin);
   for (hipEvent_t e : c->evt_pool) hipEventDestroy(e);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -514,18 +527,74 @@ int sbn_commit_rows_dev(sbn_ctx* c, const sbn_bases* b, const void* Z_dev, const
   }
   return commit_rows_device(c, b, dZ, dB, L, R, out_xy, out_inf);
 }
+// Host-pointer variant.  A large matrix is cut into row chunks: while chunk i is being committed, chunk i+1 crosses PCIe
+// into the other of two staging buffers (copy stream), so the 1 GiB of a keyless derefs commitment costs about
+// max(transfer, compute) instead of their sum.  Rows are independent (hyrax.rs:259-261), so chunking cannot change results.
 int sbn_commit_rows(sbn_ctx* c, const sbn_bases* b, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R, uint32_t flags, uint8_t* out_xy, uint8_t* out_inf) {
-  if (!c || !b || !out_xy || (!Z && L * R)) return SBN_EINVAL;
-  void* dZ = nullptr; void* dB = nullptr; int rc;
-  if ((rc = sbn_dev_alloc(c, L * R * 32, &dZ))) return rc;
-  if ((rc = sbn_dev_upload(c, dZ, Z, L * R * 32))) { sbn_dev_free(c, dZ); return rc; }
+  if (!c || !b || (!out_xy && L) || (!Z && L * R)) return SBN_EINVAL;
+  if (R != b->n) return fail(c, SBN_EINVAL, "commit: gens_n.n (%zu) != row length (%zu)  [commitments.rs:146 assert_eq]", b->n, R);
+  if (blinds && !b->has_h) return fail(c, SBN_EINVAL, "commit: blinds given but the table has no h");
+  if (L == 0) return SBN_OK;
+  std::lock_guard<std::mutex> g(c->mu);
+  hipSetDevice(c->device);
+  int rc;
+  const size_t row_bytes = R * 32;
+  size_t chunk = L;
+  size_t chunk_mb = 128;   // measured on the 1 GiB derefs matrix: 64 MB 35.0 ms, 128 MB 28.8, 256 MB 29.4, 512 MB 32.4 (one shot: 40.9)
+  if (const char* ec = getenv("SBN_COMMIT_CHUNK_MB")) { int v = atoi(ec); if (v >= 1 && v <= 4096) chunk_mb = (size_t)v; }
+  if (L * row_bytes > ((size_t)160 << 20) && row_bytes) { chunk = (chunk_mb << 20) / row_bytes; if (chunk < 1) chunk = 1; }
+  const size_t nchunks = (L + chunk - 1) / chunk;
+  if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  if ((rc = ensure(c, c->out_rows, L * 65))) return rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
+  for (int k = 0; k < (nchunks > 1 ? 2 : 1); k++) if ((rc = ensure(c, c->zstage[k], chunk * row_bytes + 64))) return rc;
+  const uint32_t* dB_all = nullptr;
   if (blinds) {
-    if ((rc = sbn_dev_alloc(c, L * 32, &dB))) { sbn_dev_free(c, dZ); return rc; }
-    if ((rc = sbn_dev_upload(c, dB, blinds, L * 32))) { sbn_dev_free(c, dZ); sbn_dev_free(c, dB); return rc; }
+    if ((rc = ensure(c, c->stage_scal, L * 64))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->stage_scal.p, blinds, L * 32, hipMemcpyHostToDevice, c->stream));
+    if (flags & SBN_SCALARS_MONT) {
+      uint32_t* o = (uint32_t*)c->stage_scal.p + 8 * L;
+      LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((L + 255) / 256), 256, (const uint32_t*)c->stage_scal.p, o, L);
+      dB_all = o;
+    } else dB_all = (const uint32_t*)c->stage_scal.p;
   }
-  rc = sbn_commit_rows_dev(c, b, dZ, dB, L, R, flags, out_xy, out_inf);
-  sbn_dev_free(c, dZ); if (dB) sbn_dev_free(c, dB);
-  return rc;
+  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; k++) { copied[k] = evt_get(c); consumed[k] = evt_get(c); }
+  uint32_t* d_xy = (uint32_t*)c->out_rows.p; uint8_t* d_inf = (uint8_t*)c->out_rows.p + L * 64;
+  rc = SBN_OK;
+  for (size_t i = 0; i < nchunks && rc == SBN_OK; i++) {
+    const int k = (int)(i & 1);
+    const size_t r0 = i * chunk, rows = std::min(chunk, L - r0);
+    // the staging buffer is free again once the chunk that used it two iterations ago has been read by its first kernels
+    if (i >= 2) { hipError_t e = hipStreamWaitEvent(c->copy_stream, consumed[k], 0); if (e != hipSuccess) { rc = fail(c, SBN_EHIP, "hipStreamWaitEvent: %s", hipGetErrorString(e)); break; } }
+    hipError_t e = hipMemcpyAsync(c->zstage[k].p, Z + r0 * row_bytes, rows * row_bytes, hipMemcpyHostToDevice, c->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(copied[k], c->copy_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, copied[k], 0);
+    if (e != hipSuccess) { rc = fail(c, SBN_EHIP, "chunk upload: %s", hipGetErrorString(e)); break; }
+    const uint32_t* dZ = (const uint32_t*)c->zstage[k].p;
+    if (flags & SBN_SCALARS_MONT) {
+      if ((rc = ensure(c, c->scal_canon, chunk * row_bytes))) break;
+      LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((rows * R + 255) / 256), 256, dZ, (uint32_t*)c->scal_canon.p, rows * R);
+      hipEventRecord(consumed[k], c->stream);
+      dZ = (const uint32_t*)c->scal_canon.p;
+      c->z_consumed = nullptr;
+    } else c->z_consumed = consumed[k];
+    rc = commit_rows_launch(c, b, dZ, dB_all ? dB_all + 8 * r0 : nullptr, rows, R, d_xy + 16 * r0, d_inf + r0);
+    c->z_consumed = nullptr;
+  }
+  if (rc == SBN_OK) {
+    hipError_t e = hipMemcpyAsync(c->pin, c->out_rows.p, L * 65, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) rc = fail(c, SBN_EHIP, "result download: %s", hipGetErrorString(e));
+  }
+  hipStreamSynchronize(c->copy_stream);
+  hipError_t es = hipStreamSynchronize(c->stream);
+  if (rc == SBN_OK && es != hipSuccess) rc = fail(c, SBN_EHIP, "commit: %s", hipGetErrorString(es));
+  for (int k = 0; k < 2; k++) { c->evt_pool.push_back(copied[k]); c->evt_pool.push_back(consumed[k]); }
+  if (c->prof) prof_drain(c);
+  if (rc) return rc;
+  memcpy(out_xy, c->pin, L * 64);
+  if (out_inf) memcpy(out_inf, (uint8_t*)c->pin + L * 64, L);
+  return SBN_OK;
 }
 
 int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32) {

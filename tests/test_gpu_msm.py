@@ -180,6 +180,54 @@ def test_commit_rows_vs_oracle(ctx, ol, L, R):
         b.free()
 
 
+def test_commit_rows_host_chunked_pipeline(ctx, ol):
+    """host-pointer commit of a matrix large enough (> 96 MB) to take the chunked path: row chunks cross PCIe while the
+    previous chunk is committed; results must equal the device-resident path and the oracle on sampled rows"""
+    import numpy as np
+    L, R = 5300, 1024                                     # 166 MB -> chunks of 4096 rows: 2 chunks, the last one ragged
+    gx, _ = ol.gens_new(R, b"gens_r1cs_sat")
+    rng = np.random.default_rng(11)
+    Z = rng.integers(0, 2**32, size=(L * R, 8), dtype=np.uint32); Z[:, 7] &= 0x0fffffff
+    Z[5 * R:6 * R] = 0
+    bl = rand_scalars(L, 12)
+    b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+    try:
+        out_h, inf_h = ctx.commit_rows(b, Z, bl, L, R)
+        d = ctx.dev_alloc(Z.nbytes); ctx.dev_upload(d, Z)
+        db = ctx.dev_alloc(len(bl)); ctx.dev_upload(db, bl)
+        out_d, inf_d = ctx.commit_rows_dev(b, d, db, L, R)
+        assert out_h == out_d and inf_h == inf_d
+        Zb = Z.tobytes()
+        for i in (0, 5, 4095, 4096, L - 1):
+            assert out_h[64 * i:64 * i + 64] == ol.commit(Zb[32 * R * i:32 * R * (i + 1)], bl[32 * i:32 * i + 32], gx[:64 * R], gx[64 * R:])
+        out_n, inf_n = ctx.commit_rows(b, Z, None, L, R)
+        assert inf_n[5] == 1 and out_n[64 * 5:64 * 6] == bytes(64)
+        ctx.dev_free(d); ctx.dev_free(db)
+    finally:
+        b.free()
+
+
+def test_two_contexts_concurrently(sbn, ol, pr):
+    """two contexts (two HIP streams + workspaces) driven from two host threads against ONE resident base table, as bench.py's
+    steps-in-flight mode and a multi-threaded caller do"""
+    import threading
+    n = 1 << 15
+    c1, c2 = sbn.Context(0), sbn.Context(0)
+    b = c1.bases_synthetic(n, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    dl = _arith_dlogs(pr, 0, n)
+    ks = [rand_scalars(n, 40 + i) for i in range(6)]
+    want = [ol.g1_mul(pr.point_to_xy(pr.G), ol.fr_dot(k, dl)) for k in ks]
+    got = [None] * 6
+
+    def work(cx, idxs):
+        for i in idxs:
+            got[i] = cx.msm_bases(b, ks[i])[0]
+    t1 = threading.Thread(target=work, args=(c1, [0, 2, 4])); t2 = threading.Thread(target=work, args=(c2, [1, 3, 5]))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert got == want
+    b.free(); c1.close(); c2.close()
+
+
 def test_commit_argument_errors(ctx, ol, sbn):
     gx, _ = ol.gens_new(8, b"x")
     b = ctx.bases_upload(gx[:64 * 8], gx[64 * 8:])
