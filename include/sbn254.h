@@ -142,6 +142,15 @@ int sbn_sc_bind_eval_quad(sbn_ctx* ctx, sbn_table* Z, sbn_table* ABC, const uint
 /* EqPolynomial::evals (hyrax.rs:355-369) built on the device */
 int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
 
+/* ---- Hyrax opening pieces ----
+ * compute_dotproduct (hyrax.rs:409-415) of two equally long tables */
+int sbn_table_dot(sbn_ctx* ctx, const sbn_table* a, const sbn_table* b, uint8_t out[32]);
+/* DensePolynomial::evaluate(r) (hyrax.rs:217-222) = <Z, eq(r)>; the eq table is built on the device (r: ell scalars, 2^ell == len) */
+int sbn_table_evaluate(sbn_ctx* ctx, const sbn_table* Z, const uint8_t* r, size_t ell, uint8_t out[32]);
+/* DensePolynomial::bound(L) (hyrax.rs:311-324), the L*Z of PolyEvalProof::prove (hyrax.rs:101): Z viewed as L_size x R_size,
+ * out[i] = sum_j Lvec[j] * Z[j*R_size + i]  (a new table of R_size entries) */
+int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn_table** out);
+
 /* ---- derefs on the device ----
  * MultiSparseMatPolynomialAsDense::deref -> AddrTimestamps::deref_mem (sparse_mlpoly_full.rs:245-257, 275-279) followed by
  * Derefs::new -> DensePolynomial::merge (sparse_mlpoly_full.rs:293-297, hyrax.rs:237-247):

@@ -26,7 +26,7 @@ typedef unsigned __int128 u128;
 typedef struct { uint64_t v[4]; } fe;
 typedef struct { fe p, r2, one; uint64_t ninv; } fctx;
 
-/* SURVEY App. A constants (re-derived numerically, see tests/test_oracle_constants.py) */
+/* SURVEY App. A constants (re-derived numerically; tests/test_oracle_golden.py::test_field_kat exercises them) */
 static const fctx FQ = {
   {{0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull}},
   {{0xf32cfc5b538afa89ull, 0xb5e71911d44501fbull, 0x47ab1eff0a417ff6ull, 0x06d89f71cab8351full}},
@@ -404,6 +404,14 @@ void orc_eq_evals(const uint8_t* r, size_t ell, uint8_t* out) {
   }
   for (size_t i = 0; i < N; i++) fe_to_bytes(&FR, out + 32 * i, &ev[i]);
   free(ev);
+}
+/* hyrax.rs:311-324 */
+void orc_bound(const uint8_t* Z, const uint8_t* L, size_t L_size, size_t R_size, uint8_t* out) {
+  for (size_t i = 0; i < R_size; i++) {
+    fe acc = {{0, 0, 0, 0}};
+    for (size_t j = 0; j < L_size; j++) { fe l, z; fe_from_bytes(&FR, &l, L + 32 * j); fe_from_bytes(&FR, &z, Z + 32 * (j * R_size + i)); fe_mul(&FR, &z, &z, &l); fe_add(&FR, &acc, &acc, &z); }
+    fe_to_bytes(&FR, out + 32 * i, &acc);
+  }
 }
 /* hyrax.rs:195-203 */
 void orc_bind_top(uint8_t* Z, size_t len, const uint8_t r[32]) {

@@ -78,6 +78,8 @@ void orc_sc_eval_quad(const uint8_t* Z, const uint8_t* ABC, size_t len, uint8_t 
 void orc_unipoly_from_evals(const uint8_t* evals, size_t n, uint8_t* coeffs);
 void orc_unipoly_eval(const uint8_t* coeffs, size_t n, const uint8_t r[32], uint8_t out[32]);
 void orc_dotproduct(const uint8_t* a, const uint8_t* b, size_t n, uint8_t out[32]);
+/* DensePolynomial::bound (hyrax.rs:311-324): out[i] = sum_j L[j] * Z[j*R_size + i], i < R_size */
+void orc_bound(const uint8_t* Z, const uint8_t* L, size_t L_size, size_t R_size, uint8_t* out);
 
 /* ---- Keccak (sha3 crate call sites: commitments.rs:33-44, group.rs:113-128) ---- */
 void orc_sha3_256(const uint8_t* in, size_t len, uint8_t out[32]);

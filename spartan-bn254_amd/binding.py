@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
 
@@ -289,6 +289,15 @@ class Context:
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()
         self._chk(lib().sbn_eq_evals(self.h, _ptr(r), C.c_size_t(ell), C.byref(ht)), "sbn_eq_evals"); return Table(self, ht)
+
+    def table_dot(self, a, b):
+        out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_dot(self.h, a.h, b.h, out), "sbn_table_dot"); return bytes(out)
+
+    def table_evaluate(self, Z, r):
+        out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_evaluate(self.h, Z.h, _ptr(r), C.c_size_t(len(r) // 32), out), "sbn_table_evaluate"); return bytes(out)
+
+    def table_bound(self, Z, Lvec):
+        ht = C.c_void_p(); self._chk(lib().sbn_table_bound(self.h, Z.h, Lvec.h, C.byref(ht)), "sbn_table_bound"); return Table(self, ht)
 
     def gather_merge(self, mems, addr_dev_ptrs, n):
         k = len(mems)

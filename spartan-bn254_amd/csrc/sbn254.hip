@@ -980,6 +980,61 @@ int sbn_sc_bind_eval_quad(sbn_ctx* c, sbn_table* Z, sbn_table* ABC, const uint8_
   sbn_table* const* cols[2] = {&Z, &ABC};
   return sc_bind_eval_common<KIND_QUAD>(c, cols, 2, 1, r, out);
 }
+static int table_dot_locked(sbn_ctx* c, const uint32_t* a, const uint32_t* b, size_t n, uint8_t out[32]) {
+  int rc;
+  unsigned gx = stream_grid(n); if (gx > 1024) gx = 1024;
+  if ((rc = ensure(c, c->sc_partial, (size_t)gx * 96))) return rc;
+  if ((rc = ensure(c, c->sc_out, 4096))) return rc;
+  if ((rc = ensure_pin(c, 4096))) return rc;
+  LAUNCH(c, "k_dot", k_dot, gx, 256, a, b, n, (uint32_t*)c->sc_partial.p);
+  LAUNCH(c, "k_sc_finish", k_sc_finish, 1, 64, (const uint32_t*)c->sc_partial.p, (int)gx, (uint32_t*)c->sc_out.p);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->sc_out.p, 32, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  memcpy(out, c->pin, 32);
+  return SBN_OK;
+}
+int sbn_table_dot(sbn_ctx* c, const sbn_table* a, const sbn_table* b, uint8_t out[32]) {
+  if (!c || !a || !b || !out) return SBN_EINVAL;
+  if (a->len != b->len) return fail(c, SBN_EINVAL, "dot: lengths differ (hyrax.rs:410 assert_eq)");
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  return table_dot_locked(c, (const uint32_t*)a->d, (const uint32_t*)b->d, a->len, out);
+}
+int sbn_table_evaluate(sbn_ctx* c, const sbn_table* Z, const uint8_t* r, size_t ell, uint8_t out[32]) {
+  if (!c || !Z || (!r && ell) || !out) return SBN_EINVAL;
+  if (((size_t)1 << ell) != Z->len) return fail(c, SBN_EINVAL, "evaluate: r.len() != num_vars (hyrax.rs:218 assert_eq)");
+  sbn_table* chi = nullptr;
+  int rc = sbn_eq_evals(c, r, ell, &chi);
+  if (rc) return rc;
+  rc = sbn_table_dot(c, Z, chi, out);
+  sbn_table_free(c, chi);
+  return rc;
+}
+int sbn_table_bound(sbn_ctx* c, const sbn_table* Z, const sbn_table* Lv, sbn_table** out) {
+  if (!c || !Z || !Lv || !out) return SBN_EINVAL;
+  const size_t L_size = Lv->len;
+  if (L_size == 0 || Z->len % L_size) return fail(c, SBN_EINVAL, "bound: table length is not a multiple of L.len()");
+  const size_t R_size = Z->len / L_size;
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  // row slices so that ~2048 blocks are in flight
+  const size_t col_tiles = (R_size + 63) / 64;
+  size_t nslices = (2048 + col_tiles - 1) / col_tiles; if (nslices > L_size) nslices = L_size; if (nslices < 1) nslices = 1;
+  const size_t rows_per_slice = (L_size + nslices - 1) / nslices; nslices = (L_size + rows_per_slice - 1) / rows_per_slice;
+  if (col_tiles > 0x7fffffff || nslices > 65535) return fail(c, SBN_EINVAL, "bound: grid too large");
+  int rc;
+  if ((rc = ensure(c, c->sc_partial, nslices * R_size * 32))) return rc;
+  sbn_table* t = new sbn_table(); t->len = R_size; t->cap = R_size;
+  hipError_t e = hipMalloc(&t->d, R_size * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc bound table: %s", hipGetErrorString(e)); }
+  LAUNCH(c, "k_bound_partial", k_bound_partial, dim3((unsigned)col_tiles, (unsigned)nslices), 256, (const uint32_t*)Z->d, (const uint32_t*)Lv->d, L_size, R_size, rows_per_slice, (uint32_t*)c->sc_partial.p);
+  LAUNCH(c, "k_bound_fold", k_bound_fold, (unsigned)((R_size + 255) / 256), 256, (const uint32_t*)c->sc_partial.p, nslices, R_size, (uint32_t*)t->d);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  *out = t;
+  return SBN_OK;
+}
 int sbn_gather_merge(sbn_ctx* c, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n, sbn_table** out) {
   if (!c || !mem || !addr_dev || !out || count == 0 || n == 0) return SBN_EINVAL;
   for (size_t k = 0; k < count; k++) if (!mem[k] || !addr_dev[k]) return SBN_EINVAL;

@@ -188,6 +188,50 @@ __global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ i
     fe_store<FrP>(out + 8 * (2 * k), fe_sub(s, hi));
   }
 }
+// <a, b> partial sums: partial[block] (Montgomery); finished by k_sc_finish-style fold on one value
+__global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ partial) {
+  Fr acc = fe_zero<FrP>();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc = fe_add(acc, fe_mul(fe_load<FrP>(a + 8 * i), fe_load<FrP>(b + 8 * i)));
+  __shared__ uint32_t sm[4][8];
+  acc = wave_sum_fr(acc);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) for (int k = 0; k < 8; k++) sm[wv][k] = acc.v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
+    // stored in the 3-slot layout of k_sc_finish (slots 1, 2 zero)
+    uint32_t* o = partial + 8 * ((size_t)blockIdx.x * 3);
+    for (int k = 0; k < 8; k++) { o[k] = s.v[k]; o[8 + k] = 0; o[16 + k] = 0; }
+  }
+}
+// L*Z: block (column tile of 64, row slice): lanes own columns (coalesced 2 KiB rows), the block's 4 waves split the row
+// slice; partial[slice][col] then folded by k_bound_fold.  Z is L_size x R_size row-major.
+__global__ void __launch_bounds__(256) k_bound_partial(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ Lv, size_t L_size, size_t R_size, size_t rows_per_slice, uint32_t* __restrict__ partial) {
+  const size_t col = (size_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int wv = threadIdx.x >> 6;
+  const size_t j0 = (size_t)blockIdx.y * rows_per_slice, j1 = (j0 + rows_per_slice < L_size) ? j0 + rows_per_slice : L_size;
+  Fr acc = fe_zero<FrP>();
+  if (col < R_size)
+    for (size_t j = j0 + wv; j < j1; j += 4) acc = fe_add(acc, fe_mul(fe_load<FrP>(Lv + 8 * j), fe_load<FrP>(Z + 8 * (j * R_size + col))));
+  __shared__ uint32_t sm[4][64][8];
+  for (int k = 0; k < 8; k++) sm[wv][threadIdx.x & 63][k] = acc.v[k];
+  __syncthreads();
+  if (wv == 0 && col < R_size) {
+    Fr s = acc;
+    for (int w = 1; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][threadIdx.x & 63][k]; s = fe_add(s, x); }
+    fe_store<FrP>(partial + 8 * ((size_t)blockIdx.y * R_size + col), s);
+  }
+}
+__global__ void __launch_bounds__(256) k_bound_fold(const uint32_t* __restrict__ partial, size_t nslices, size_t R_size, uint32_t* __restrict__ out) {
+  const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= R_size) return;
+  Fr s = fe_zero<FrP>();
+  for (size_t k = 0; k < nslices; k++) s = fe_add(s, fe_load<FrP>(partial + 8 * (k * R_size + col)));
+  fe_store<FrP>(out + 8 * col, s);
+}
+
 // out[k*n + i] = mem[k][addr[k][i]]  (AddrTimestamps::deref_mem, sparse_mlpoly_full.rs:245-252), zero padding past count*n
 struct GatherArgs { const uint32_t* mem; const uint32_t* addr; size_t mem_len; };
 __global__ void __launch_bounds__(256) k_gather_merge(const GatherArgs* __restrict__ args, size_t count, size_t n, size_t padded, uint32_t* __restrict__ out, uint32_t* __restrict__ oob) {

@@ -114,6 +114,10 @@ def eq_evals(r):
     ell = len(r) // 32; out = _buf(32 << ell); lib().orc_eq_evals(r, C.c_size_t(ell), out); return _b(out)
 
 
+def bound(Z, L, L_size, R_size):
+    out = _buf(32 * R_size); lib().orc_bound(Z, L, C.c_size_t(L_size), C.c_size_t(R_size), out); return _b(out)
+
+
 def bind_top(Z, r):
     n = len(Z) // 32; buf = (C.c_uint8 * len(Z)).from_buffer_copy(Z); lib().orc_bind_top(buf, C.c_size_t(n), r); return _b(buf)[: 32 * (n // 2)]
 

@@ -232,3 +232,33 @@ def test_derefs_gather_and_commit(ctx, ol, pr, sbn):
     for t in (comb, mem_rx, mem_ry):
         t.free()
     bases.free()
+
+
+@pytest.mark.parametrize("ell", [1, 4, 9, 13])
+def test_opening_pieces_vs_oracle(ctx, ol, sbn, ell):
+    """SURVEY 8f-2, the vector work of PolyEvalProof::prove (hyrax.rs:65-116): L, R = compute_factored_evals (hyrax.rs:375-383),
+    LZ = poly.bound(L) (hyrax.rs:311-324), evaluate (hyrax.rs:217-222) and the identity <LZ, R> == Z(r)."""
+    n = 1 << ell
+    Z = rand_scalars(n, 100 + ell); r = rand_scalars(ell, 200 + ell)
+    tZ = ctx.table_upload(Z)
+    lv, rv = sbn.factored_lens(ell)
+    L_size, R_size = 1 << lv, 1 << rv
+    tL, tR = ctx.eq_evals(r[:32 * lv]), ctx.eq_evals(r[32 * lv:])
+    hL = ol.eq_evals(r[:32 * lv]) if lv else (1).to_bytes(32, "little")
+    hR = ol.eq_evals(r[32 * lv:])
+    tLZ = ctx.table_bound(tZ, tL)
+    want_LZ = ol.bound(Z, hL, L_size, R_size)
+    assert len(tLZ) == R_size and ctx.table_download(tLZ) == want_LZ
+    zr = ctx.table_evaluate(tZ, r)
+    assert zr == ol.fr_dot(Z, ol.eq_evals(r))
+    assert ctx.table_dot(tLZ, tR) == zr == ol.fr_dot(want_LZ, hR)
+    for t in (tZ, tL, tR, tLZ):
+        t.free()
+
+
+def test_dense_poly_reference_evaluate(ctx):
+    """hyrax.rs:435-453: Z=[1,2,3,4] evaluates to 1 at (0,0) and 4 at (1,1)"""
+    t = ctx.table_upload(fr_bytes([1, 2, 3, 4]))
+    assert ctx.table_evaluate(t, fr_bytes([0, 0])) == fr_bytes([1])
+    assert ctx.table_evaluate(t, fr_bytes([1, 1])) == fr_bytes([4])
+    t.free()
