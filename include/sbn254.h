@@ -151,6 +151,18 @@ int sbn_table_evaluate(sbn_ctx* ctx, const sbn_table* Z, const uint8_t* r, size_
  * out[i] = sum_j Lvec[j] * Z[j*R_size + i]  (a new table of R_size entries) */
 int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn_table** out);
 
+/* ---- network construction pieces ----
+ * Layers::build_hash_layer (sparse_mlpoly_full.rs:745-796): out[j] = (ts[j] + ts_add) * r_hash^2 + val[j] * r_hash + addr[j] - r_multiset
+ * addr_dev / ts_dev: DEVICE arrays of n uint32 (NULL addr = the cell index j, as for poly_init/audit_hashed; NULL ts = zeros);
+ * ts_add = 1 gives the write set (read_ts + 1).  val: table of n entries (eval_table or a derefs poly). */
+int sbn_hash_layer(sbn_ctx* ctx, const void* addr_dev, const sbn_table* val, const void* ts_dev, uint32_t ts_add,
+                   const uint8_t r_hash[32], const uint8_t r_multiset[32], sbn_table** out);
+/* ProductCircuit::compute_layer (product_tree.rs:21-37): the next layer's full vector out[i] = in[i] * in[i + len/2] */
+int sbn_product_layer(sbn_ctx* ctx, const sbn_table* in, sbn_table** out);
+/* DensePolynomial::split(len/2) (hyrax.rs:186-192) as views: left = first half, right = second half of `t` (the A and B tables of
+ * a product-circuit layer).  Views share t's memory and must be freed before t. */
+int sbn_table_halves(sbn_ctx* ctx, const sbn_table* t, sbn_table** left, sbn_table** right);
+
 /* ---- derefs on the device ----
  * MultiSparseMatPolynomialAsDense::deref -> AddrTimestamps::deref_mem (sparse_mlpoly_full.rs:245-257, 275-279) followed by
  * Derefs::new -> DensePolynomial::merge (sparse_mlpoly_full.rs:293-297, hyrax.rs:237-247):

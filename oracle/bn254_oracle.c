@@ -405,6 +405,20 @@ void orc_eq_evals(const uint8_t* r, size_t ell, uint8_t* out) {
   for (size_t i = 0; i < N; i++) fe_to_bytes(&FR, out + 32 * i, &ev[i]);
   free(ev);
 }
+/* sparse_mlpoly_full.rs:756-758: hash_func(addr, val, ts) = ts*r_hash^2 + val*r_hash + addr, minus r_multiset_check */
+void orc_hash_layer(const uint32_t* addr, const uint8_t* val, const uint32_t* ts, uint32_t ts_add, const uint8_t g[32], const uint8_t tau[32], size_t n, uint8_t* out) {
+  fe gg, g2, tt; fe_from_bytes(&FR, &gg, g); fe_sqr(&FR, &g2, &gg); fe_from_bytes(&FR, &tt, tau);
+  for (size_t j = 0; j < n; j++) {
+    fe a, v, t, acc;
+    fe_from_u64(&FR, &a, addr ? addr[j] : (uint64_t)j); fe_from_bytes(&FR, &v, val + 32 * j); fe_from_u64(&FR, &t, (uint64_t)(ts ? ts[j] : 0) + ts_add);
+    fe_mul(&FR, &acc, &t, &g2); fe_mul(&FR, &v, &v, &gg); fe_add(&FR, &acc, &acc, &v); fe_add(&FR, &acc, &acc, &a); fe_sub(&FR, &acc, &acc, &tt);
+    fe_to_bytes(&FR, out + 32 * j, &acc);
+  }
+}
+/* product_tree.rs:21-37 */
+void orc_product_layer(const uint8_t* in, size_t len, uint8_t* out) {
+  for (size_t i = 0; i < len / 2; i++) { fe a, b; fe_from_bytes(&FR, &a, in + 32 * i); fe_from_bytes(&FR, &b, in + 32 * (i + len / 2)); fe_mul(&FR, &a, &a, &b); fe_to_bytes(&FR, out + 32 * i, &a); }
+}
 /* hyrax.rs:311-324 */
 void orc_bound(const uint8_t* Z, const uint8_t* L, size_t L_size, size_t R_size, uint8_t* out) {
   for (size_t i = 0; i < R_size; i++) {

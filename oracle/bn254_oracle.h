@@ -81,6 +81,12 @@ void orc_dotproduct(const uint8_t* a, const uint8_t* b, size_t n, uint8_t out[32
 /* DensePolynomial::bound (hyrax.rs:311-324): out[i] = sum_j L[j] * Z[j*R_size + i], i < R_size */
 void orc_bound(const uint8_t* Z, const uint8_t* L, size_t L_size, size_t R_size, uint8_t* out);
 
+/* Layers::build_hash_layer (sparse_mlpoly_full.rs:745-796): out[j] = (ts[j] + ts_add) * g^2 + val[j] * g + addr[j] - tau.
+ * addr / ts: n uint32 each; NULL addr = identity (cell index j), NULL ts = zeros */
+void orc_hash_layer(const uint32_t* addr, const uint8_t* val, const uint32_t* ts, uint32_t ts_add, const uint8_t g[32], const uint8_t tau[32], size_t n, uint8_t* out);
+/* ProductCircuit::compute_layer (product_tree.rs:21-37): out[i] = in[i] * in[i + len/2], i < len/2 */
+void orc_product_layer(const uint8_t* in, size_t len, uint8_t* out);
+
 /* ---- Keccak (sha3 crate call sites: commitments.rs:33-44, group.rs:113-128) ---- */
 void orc_sha3_256(const uint8_t* in, size_t len, uint8_t out[32]);
 void orc_shake256(const uint8_t* in, size_t len, uint8_t* out, size_t outlen);

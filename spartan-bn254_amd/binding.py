@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
 
@@ -289,6 +289,18 @@ class Context:
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()
         self._chk(lib().sbn_eq_evals(self.h, _ptr(r), C.c_size_t(ell), C.byref(ht)), "sbn_eq_evals"); return Table(self, ht)
+
+    def hash_layer(self, addr_dev_ptr, val, ts_dev_ptr, ts_add, r_hash, r_multiset):
+        ht = C.c_void_p()
+        self._chk(lib().sbn_hash_layer(self.h, C.c_void_p(addr_dev_ptr or 0), val.h, C.c_void_p(ts_dev_ptr or 0), C.c_uint32(ts_add), _ptr(r_hash), _ptr(r_multiset), C.byref(ht)), "sbn_hash_layer")
+        return Table(self, ht)
+
+    def product_layer(self, t):
+        ht = C.c_void_p(); self._chk(lib().sbn_product_layer(self.h, t.h, C.byref(ht)), "sbn_product_layer"); return Table(self, ht)
+
+    def table_halves(self, t):
+        l, r = C.c_void_p(), C.c_void_p()
+        self._chk(lib().sbn_table_halves(self.h, t.h, C.byref(l), C.byref(r)), "sbn_table_halves"); return Table(self, l), Table(self, r)
 
     def table_dot(self, a, b):
         out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_dot(self.h, a.h, b.h, out), "sbn_table_dot"); return bytes(out)

@@ -69,7 +69,7 @@ extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);
 
 struct sbn_table {
   void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
-  void* d2 = nullptr; size_t cap2 = 0;     // second buffer for the fused (out-of-place) bind
+  void* d2 = nullptr; size_t cap2 = 0; bool owned2 = true;     // second buffer for the fused (out-of-place) bind
 };
 
 static int fail(sbn_ctx* c, int code, const char* fmt, ...) {
@@ -802,7 +802,7 @@ int sbn_table_from_dev(sbn_ctx* c, const void* Z_dev, size_t len, uint32_t flags
   std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
   return table_make(c, Z_dev, false, len, flags, out);
 }
-void sbn_table_free(sbn_ctx* c, sbn_table* t) { if (!t) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (t->d && t->owned) hipFree(t->d); if (t->d2) hipFree(t->d2); delete t; }
+void sbn_table_free(sbn_ctx* c, sbn_table* t) { if (!t) return; if (c) { hipSetDevice(c->device); hipStreamSynchronize(c->stream); } if (t->d && t->owned) hipFree(t->d); if (t->d2 && t->owned2) hipFree(t->d2); delete t; }
 size_t sbn_table_len(const sbn_table* t) { return t ? t->len : 0; }
 int sbn_table_download(sbn_ctx* c, const sbn_table* t, uint8_t* out) {
   if (!c || !t || !out) return SBN_EINVAL;
@@ -935,7 +935,8 @@ static int sc_bind_eval_common(sbn_ctx* c, sbn_table* const* const* cols, int nc
     ha[i].src[j] = (const uint32_t*)t->d;
     if (std::find(distinct.begin(), distinct.end(), t) == distinct.end()) {
       if (t->cap2 < len / 2) {
-        if (t->d2) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(t->d2)); t->d2 = nullptr; t->cap2 = 0; }
+        if (t->d2) { HIPCHK(c, hipStreamSynchronize(c->stream)); if (t->owned2) HIPCHK(c, hipFree(t->d2)); t->d2 = nullptr; t->cap2 = 0; }
+        t->owned2 = true;
         hipError_t e = hipMalloc(&t->d2, (len / 2) * 32);
         if (e != hipSuccess) return fail(c, SBN_ENOMEM, "hipMalloc second table buffer: %s", hipGetErrorString(e));
         t->cap2 = len / 2;
@@ -956,7 +957,7 @@ static int sc_bind_eval_common(sbn_ctx* c, sbn_table* const* const* cols, int nc
   HIPCHK(c, hipMemcpyAsync(hres, c->sc_out.p, count * 96, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof) prof_drain(c);
-  for (sbn_table* t : distinct) { std::swap(t->d, t->d2); std::swap(t->cap, t->cap2); t->len = len / 2; }
+  for (sbn_table* t : distinct) { std::swap(t->d, t->d2); std::swap(t->cap, t->cap2); std::swap(t->owned, t->owned2); t->len = len / 2; }
   if (KIND == KIND_QUAD) { for (size_t i = 0; i < count; i++) memcpy(out + 64 * i, hres + 96 * i, 64); }
   else memcpy(out, hres, count * 96);
   return SBN_OK;
@@ -979,6 +980,52 @@ int sbn_sc_bind_eval_quad(sbn_ctx* c, sbn_table* Z, sbn_table* ABC, const uint8_
   std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
   sbn_table* const* cols[2] = {&Z, &ABC};
   return sc_bind_eval_common<KIND_QUAD>(c, cols, 2, 1, r, out);
+}
+int sbn_hash_layer(sbn_ctx* c, const void* addr_dev, const sbn_table* val, const void* ts_dev, uint32_t ts_add, const uint8_t r_hash[32], const uint8_t r_multiset[32], sbn_table** out) {
+  if (!c || !val || !r_hash || !r_multiset || !out) return SBN_EINVAL;
+  if (!fr_canonical(r_hash) || !fr_canonical(r_multiset)) return fail(c, SBN_EINVAL, "hash layer: challenges not canonical");
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  const size_t n = val->len; int rc;
+  if ((rc = ensure(c, c->sc_r, 64 + 96))) return rc;
+  if ((rc = ensure_pin(c, 4096))) return rc;
+  memcpy(c->pin, r_hash, 32); memcpy((uint8_t*)c->pin + 32, r_multiset, 32);
+  HIPCHK(c, hipMemcpyAsync(c->sc_r.p, c->pin, 64, hipMemcpyHostToDevice, c->stream));
+  uint32_t* consts = (uint32_t*)c->sc_r.p + 16;
+  LAUNCH(c, "k_hash_consts", k_hash_consts, 1, 64, (const uint32_t*)c->sc_r.p, consts);
+  sbn_table* t = new sbn_table(); t->len = n; t->cap = n;
+  hipError_t e = hipMalloc(&t->d, n * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc hash layer: %s", hipGetErrorString(e)); }
+  LAUNCH(c, "k_hash_layer", k_hash_layer, stream_grid(n), 256, (const uint32_t*)addr_dev, (const uint32_t*)val->d, (const uint32_t*)ts_dev, ts_add, (const uint32_t*)consts, n, (uint32_t*)t->d);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  *out = t;
+  return SBN_OK;
+}
+int sbn_product_layer(sbn_ctx* c, const sbn_table* in, sbn_table** out) {
+  if (!c || !in || !out) return SBN_EINVAL;
+  if (in->len < 2) return fail(c, SBN_EINVAL, "product layer: nothing left to multiply");
+  std::lock_guard<std::mutex> g(c->mu); hipSetDevice(c->device);
+  const size_t half = in->len / 2;
+  sbn_table* t = new sbn_table(); t->len = half; t->cap = half;
+  hipError_t e = hipMalloc(&t->d, half * 32);
+  if (e != hipSuccess) { delete t; return fail(c, SBN_ENOMEM, "hipMalloc product layer: %s", hipGetErrorString(e)); }
+  LAUNCH(c, "k_product_layer", k_product_layer, stream_grid(half), 256, (const uint32_t*)in->d, half, (uint32_t*)t->d);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  *out = t;
+  return SBN_OK;
+}
+int sbn_table_halves(sbn_ctx* c, const sbn_table* t, sbn_table** left, sbn_table** right) {
+  if (!c || !t || !left || !right) return SBN_EINVAL;
+  if (t->len < 2) return fail(c, SBN_EINVAL, "halves: table has one entry");
+  const size_t half = t->len / 2;
+  sbn_table* l = new sbn_table(); sbn_table* r = new sbn_table();
+  l->d = t->d; l->len = l->cap = half; l->owned = false;
+  r->d = (uint8_t*)t->d + half * 32; r->len = r->cap = half; r->owned = false;
+  *left = l; *right = r;
+  return SBN_OK;
 }
 static int table_dot_locked(sbn_ctx* c, const uint32_t* a, const uint32_t* b, size_t n, uint8_t out[32]) {
   int rc;

@@ -188,6 +188,37 @@ __global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ i
     fe_store<FrP>(out + 8 * (2 * k), fe_sub(s, hi));
   }
 }
+// hash layer: out[j] = (ts[j]+ts_add)*g^2 + val[j]*g + addr[j] - tau.  g2rr = g^2 * R (a "doubly Montgomery" value), so one
+// Montgomery product with the plain small integer ts gives mont(ts*g^2); rr = R^2 turns the plain addr into mont(addr).
+__global__ void __launch_bounds__(256) k_hash_layer(const uint32_t* __restrict__ addr, const uint32_t* __restrict__ val, const uint32_t* __restrict__ ts, uint32_t ts_add,
+                                                    const uint32_t* __restrict__ consts /* g, g2rr, tau : Montgomery */, size_t n, uint32_t* __restrict__ out) {
+  const Fr g = fe_load<FrP>(consts), g2rr = fe_load<FrP>(consts + 8), tau = fe_load<FrP>(consts + 16);
+  Fr rr; for (int k = 0; k < 8; k++) rr.v[k] = FrP::R2[k];
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    Fr a = fe_zero<FrP>(), t = fe_zero<FrP>();
+    const unsigned long long av = addr ? addr[j] : (unsigned long long)j;
+    a.v[0] = (uint32_t)av; a.v[1] = (uint32_t)(av >> 32);
+    const unsigned long long tv = (unsigned long long)(ts ? ts[j] : 0u) + ts_add;
+    t.v[0] = (uint32_t)tv; t.v[1] = (uint32_t)(tv >> 32);
+    Fr acc = fe_mul(g2rr, t);
+    acc = fe_add(acc, fe_mul(fe_load<FrP>(val + 8 * j), g));
+    acc = fe_add(acc, fe_mul(rr, a));
+    fe_store<FrP>(out + 8 * j, fe_sub(acc, tau));
+  }
+}
+__global__ void __launch_bounds__(256) k_product_layer(const uint32_t* __restrict__ in, size_t half, uint32_t* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+    fe_store<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
+}
+// g (canonical) -> {mont(g), g^2 * R^2 mod r (= mont(mont(g^2))), mont(tau)}
+__global__ void k_hash_consts(const uint32_t* __restrict__ g_tau_canon, uint32_t* __restrict__ consts) {
+  if (threadIdx.x || blockIdx.x) return;
+  const Fr gm = fe_to_mont(fe_load<FrP>(g_tau_canon)), tm = fe_to_mont(fe_load<FrP>(g_tau_canon + 8));
+  fe_store<FrP>(consts, gm);
+  fe_store<FrP>(consts + 8, fe_to_mont(fe_mul(gm, gm)));
+  fe_store<FrP>(consts + 16, tm);
+}
+
 // <a, b> partial sums: partial[block] (Montgomery); finished by k_sc_finish-style fold on one value
 __global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, size_t n, uint32_t* __restrict__ partial) {
   Fr acc = fe_zero<FrP>();

@@ -114,6 +114,18 @@ def eq_evals(r):
     ell = len(r) // 32; out = _buf(32 << ell); lib().orc_eq_evals(r, C.c_size_t(ell), out); return _b(out)
 
 
+def hash_layer(addr, val, ts, ts_add, g, tau):
+    """addr / ts: numpy uint32 arrays or None"""
+    n = len(val) // 32; out = _buf(32 * n)
+    ap = addr.ctypes.data_as(C.c_void_p) if addr is not None else None
+    tp = ts.ctypes.data_as(C.c_void_p) if ts is not None else None
+    lib().orc_hash_layer(ap, val, tp, C.c_uint32(ts_add), g, tau, C.c_size_t(n), out); return _b(out)
+
+
+def product_layer(v):
+    n = len(v) // 32; out = _buf(16 * n); lib().orc_product_layer(v, C.c_size_t(n), out); return _b(out)
+
+
 def bound(Z, L, L_size, R_size):
     out = _buf(32 * R_size); lib().orc_bound(Z, L, C.c_size_t(L_size), C.c_size_t(R_size), out); return _b(out)
 

@@ -262,3 +262,57 @@ def test_dense_poly_reference_evaluate(ctx):
     assert ctx.table_evaluate(t, fr_bytes([0, 0])) == fr_bytes([1])
     assert ctx.table_evaluate(t, fr_bytes([1, 1])) == fr_bytes([4])
     t.free()
+
+
+def test_network_construction_pieces(ctx, ol, pr):
+    """SURVEY 8f-3: Layers::build_hash_layer (sparse_mlpoly_full.rs:745-796) and ProductCircuit::new (product_tree.rs:39-57) on the
+    device, then the layer-0 cubic sumcheck of the product circuit on the halves views (product_tree.rs:267-332)."""
+    import numpy as np
+    ell, nops = 7, 64
+    rx = rand_scalars(ell, 1)
+    mem = ctx.eq_evals(rx); hmem = ol.eq_evals(rx)
+    rng = np.random.default_rng(3)
+    addr = rng.integers(0, 1 << ell, size=nops, dtype=np.uint32)
+    ts = rng.integers(0, 50, size=nops, dtype=np.uint32)
+    audit = rng.integers(0, 9, size=1 << ell, dtype=np.uint32)
+    g, tau = rand_scalars(1, 5), rand_scalars(1, 6)
+    d_addr = ctx.dev_alloc(addr.nbytes); ctx.dev_upload(d_addr, addr.tobytes())
+    d_ts = ctx.dev_alloc(ts.nbytes); ctx.dev_upload(d_ts, ts.tobytes())
+    d_au = ctx.dev_alloc(audit.nbytes); ctx.dev_upload(d_au, audit.tobytes())
+    deref = ctx.gather_merge([mem], [d_addr], nops)                      # row_ops_val for this matrix
+    hderef = b"".join(hmem[32 * int(a):32 * int(a) + 32] for a in addr)
+    t_init = ctx.hash_layer(None, mem, None, 0, g, tau)
+    t_audit = ctx.hash_layer(None, mem, d_au, 0, g, tau)
+    t_read = ctx.hash_layer(d_addr, deref, d_ts, 0, g, tau)
+    t_write = ctx.hash_layer(d_addr, deref, d_ts, 1, g, tau)
+    assert ctx.table_download(t_init) == ol.hash_layer(None, hmem, None, 0, g, tau)
+    assert ctx.table_download(t_audit) == ol.hash_layer(None, hmem, audit, 0, g, tau)
+    assert ctx.table_download(t_read) == ol.hash_layer(addr, hderef, ts, 0, g, tau)
+    assert ctx.table_download(t_write) == ol.hash_layer(addr, hderef, ts, 1, g, tau)
+    # product circuit layers of the read set, down to two entries, against the oracle; evaluate() = product of everything
+    cur, hcur = t_read, ol.hash_layer(addr, hderef, ts, 0, g, tau)
+    layers = [cur]
+    while len(cur) > 2:
+        nxt = ctx.product_layer(cur); hcur = ol.product_layer(hcur)
+        assert ctx.table_download(nxt) == hcur
+        layers.append(nxt); cur = nxt
+    total = 1
+    hr = ol.hash_layer(addr, hderef, ts, 0, g, tau)
+    for j in range(nops):
+        total = total * int.from_bytes(hr[32 * j:32 * j + 32], "little") % pr.R
+    assert int.from_bytes(hcur[:32], "little") * int.from_bytes(hcur[32:], "little") % pr.R == total
+    # halves views feed the sumcheck: sum_i left[i]*right[i]*eq[i] over layer 0 (product_tree.rs:271-332)
+    left, right = ctx.table_halves(layers[0])
+    hl, hrr = hr[:32 * nops // 2], hr[32 * nops // 2:]
+    assert ctx.table_download(left) == hl and ctx.table_download(right) == hrr
+    eqr = rand_scalars(5, 8); tC = ctx.eq_evals(eqr); hC = ol.eq_evals(eqr)
+    assert ctx.sc_eval_cubic(left, right, tC) == ol.sc_eval_cubic(hl, hrr, hC)
+    r = rand_scalars(1, 9)
+    assert ctx.sc_bind_eval_cubic_batched([left], [right], [tC], r) == ol.sc_eval_cubic(ol.bind_top(hl, r), ol.bind_top(hrr, r), ol.bind_top(hC, r))
+    assert ctx.table_download(left) == ol.bind_top(hl, r)                 # the view now lives in its own second buffer
+    for t in (left, right, tC):
+        t.free()
+    for t in layers[1:] + [t_init, t_audit, t_read, t_write, deref, mem]:
+        t.free()
+    for p in (d_addr, d_ts, d_au):
+        ctx.dev_free(p)
