@@ -1,0 +1,101 @@
+// ctx.hpp — context, workspace and per-kernel profiling of libsbn254_hip.so (included by sbn254.hip only).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+struct ProfEntry { std::string name; double ms = 0; uint64_t launches = 0; };
+struct PendingEvt { int idx; hipEvent_t e0, e1; };
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+};
+
+struct sbn_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::mutex mu;
+  std::string err;
+  // workspace (grown on demand, never shrunk; no allocation in steady state)
+  DevBuf scal_canon, hist, offs, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
+  hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
+  hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
+  DevBuf zstage[2], out_rows;
+  bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
+  int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
+  void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
+  // profiling
+  bool prof = false;
+  std::vector<ProfEntry> prof_entries;
+  std::vector<PendingEvt> prof_pending;
+  std::vector<hipEvent_t> evt_pool;
+};
+
+struct sbn_bases {
+  size_t n = 0;           // number of G points
+  bool has_h = false;
+  void* d_pts = nullptr;  // (n + has_h) x 64 B, Montgomery affine
+  mutable std::unordered_map<int, void*> tables;   // window bits c -> W x (n + has_h) x 64 B: 2^(c w) * P_j (built on first commit)
+  // equal bases merged (commit path): unique points as their own table + CSR of the columns that map to each
+  sbn_bases* uniq = nullptr;
+  size_t U = 0; uint32_t nbig = 0;
+  void* d_csr_off = nullptr; void* d_csr_cols = nullptr; void* d_big = nullptr;
+};
+static const uint32_t MERGE_BIG = 64;
+extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);
+
+struct sbn_table {
+  void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
+  void* d2 = nullptr; size_t cap2 = 0; bool owned2 = true;     // second buffer for the fused (out-of-place) bind
+};
+
+static int fail(sbn_ctx* c, int code, const char* fmt, ...) {
+  char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail((c), SBN_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+static int ensure(sbn_ctx* c, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return SBN_OK;
+  if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + (bytes >> 3);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return fail(c, SBN_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
+  b.cap = want;
+  return SBN_OK;
+}
+static int ensure_pin(sbn_ctx* c, size_t bytes) {
+  if (bytes <= c->pin_cap) return SBN_OK;
+  if (c->pin) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+  HIPCHK(c, hipHostMalloc(&c->pin, bytes, hipHostMallocDefault));
+  c->pin_cap = bytes;
+  return SBN_OK;
+}
+
+// ---- profiling: HIP events around every launch on the stream the kernel runs on ----
+static int prof_index(sbn_ctx* c, const char* name) {
+  for (size_t i = 0; i < c->prof_entries.size(); i++) if (c->prof_entries[i].name == name) return (int)i;
+  ProfEntry e; e.name = name; c->prof_entries.push_back(e); return (int)c->prof_entries.size() - 1;
+}
+static hipEvent_t evt_get(sbn_ctx* c) {
+  if (!c->evt_pool.empty()) { hipEvent_t e = c->evt_pool.back(); c->evt_pool.pop_back(); return e; }
+  hipEvent_t e; hipEventCreate(&e); return e;
+}
+static void prof_drain(sbn_ctx* c) {
+  for (auto& p : c->prof_pending) {
+    hipEventSynchronize(p.e1);
+    float ms = 0; hipEventElapsedTime(&ms, p.e0, p.e1);
+    c->prof_entries[p.idx].ms += ms; c->prof_entries[p.idx].launches += 1;
+    c->evt_pool.push_back(p.e0); c->evt_pool.push_back(p.e1);
+  }
+  c->prof_pending.clear();
+}
+struct ProfScope {
+  sbn_ctx* c; PendingEvt pe; bool on;
+  ProfScope(sbn_ctx* c_, const char* name) : c(c_), on(c_->prof) {
+    if (on) { pe.idx = prof_index(c, name); pe.e0 = evt_get(c); pe.e1 = evt_get(c); hipEventRecord(pe.e0, c->stream); }
+  }
+  ~ProfScope() { if (on) { hipEventRecord(pe.e1, c->stream); c->prof_pending.push_back(pe); } }
+};
+#define LAUNCH(c, name, kern, grid, block, ...) \
+  do { ProfScope _ps((c), name); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); } while (0)
+#define LAUNCHCHK(c) HIPCHK(c, hipGetLastError())

@@ -1,0 +1,278 @@
+// msm_host.hpp — launch code of the MSM / commitment path: window choice, the bucket pipeline (digits -> LDS counting sort ->
+// load-ordered accumulation -> reduction), window tables, merging of equal bases, row-chunk launches.
+// Reference boundary: group.rs:171-175, commitments.rs:144-154, hyrax.rs:253-308 (included by sbn254.hip only).
+#pragma once
+// ------------------------------------------------------------------------------------------------
+static int ilog2_ceil(size_t n) { int l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// Signed radix-2^c digits: W windows cover 254 bits, the top digit (+ carry) must stay <= 2^(c-1).
+static MsmShape make_shape(int c) {
+  MsmShape s; s.c = c; s.nb = 1 << (c - 1);
+  int W = (254 + c - 1) / c;
+  int tb = 254 - (W - 1) * c;          // bits in the top window
+  if (tb > c - 1) W += 1;
+  s.W = W;
+  return s;
+}
+// Window size from a cost model in modular products: `terms`*W mixed adds (10 each) into `sets` bucket sets of 2^(c-1)
+// buckets, each bucket costing ~2 full adds (14 each) in the running-sum reduction (x2 for the wave-level part).
+// SBN_MSM_C overrides for experiments.
+static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax) {
+  const char* env = getenv("SBN_MSM_C");
+  if (env && atoi(env) >= 7 && atoi(env) <= 22) return make_shape(atoi(env));
+  double best = 1e300; int bc = 7;
+  // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
+  // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows.
+  for (int c = 7; c <= cmax; c++) {
+    MsmShape s = make_shape(c);
+    double sets = shared_bucket_set ? 1.0 : (double)s.W;
+    double cost = (double)terms * s.W * 10.0 + sets * s.nb * 56.0;
+    if (cost < best) { best = cost; bc = c; }
+  }
+  return make_shape(bc);
+}
+
+struct BucketJob {
+  int mode; DigitArgs da; MsmShape s;
+  size_t P;               // problems (windows or rows)
+  size_t threads;         // digit-kernel threads
+  const uint32_t* points; // Montgomery affine points the entries index
+};
+
+// digits -> counting sort -> segmented bucket accumulation -> per-problem weighted sums in c->wsum (P x XYZZ)
+static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
+  const MsmShape& s = J.s;
+  const size_t NB = J.P * (size_t)s.nb;
+  if (NB > 0xffffffffull) return fail(c, SBN_EINVAL, "bucket space too large");
+  const size_t estride = J.da.estride;
+  // segment length: twice the mean bucket load (power of two, >= 32)
+  size_t mean = estride / (size_t)s.nb + 1;
+  uint32_t SEG = 32; while (SEG < 2 * mean && SEG < ACC_SEG_MAX) SEG <<= 1;
+  // enough segments to fill the chip when a problem has few, heavily loaded buckets (one row, many columns)
+  if (NB < 262144) { const size_t total = J.P * estride; uint32_t cap = 32; while ((size_t)cap * 262144 < total && cap < ACC_SEG_MAX) cap <<= 1; if (SEG > cap) SEG = cap; }
+  if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
+  const size_t max_extra = J.P * estride / SEG + 1;
+  const size_t max_big = std::min(NB, max_extra);
+  int rc;
+  if ((rc = ensure(c, c->hist, NB * 4))) return rc;
+  if ((rc = ensure(c, c->offs, NB * 4))) return rc;
+  if ((rc = ensure(c, c->sorted, J.P * estride * 4))) return rc;
+  if ((rc = ensure(c, c->buckets, NB * 128))) return rc;
+  if ((rc = ensure(c, c->acc_ctr, 64))) return rc;
+  if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
+  if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
+  if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
+  // buckets per lane in the reduction: few buckets -> short lane chains and more waves (latency-bound regime); many buckets ->
+  // longer chains amortise the wave-level scan/tree (throughput-bound regime).  Aim for ~2048 waves.
+  int L = 1; while ((size_t)L * 64 * 2048 < NB && L < 16) L <<= 1;
+  if (L < 4) L = 4;
+  if (L > s.nb / 64) L = s.nb / 64;
+  if (L < 1) L = 1;
+  if (const char* el = getenv("SBN_RED_L")) { int v = atoi(el); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= s.nb / 64) L = v; }
+  int logL = 0; while ((1 << logL) < L) logL++;
+  const int chunks = s.nb / (64 * L);                     // per problem, >= 1
+  if ((rc = ensure(c, c->red_a, J.P * chunks * 256))) return rc;
+  if ((rc = ensure(c, c->red_b, J.P * ((chunks + 63) / 64) * 256))) return rc;
+  if ((rc = ensure(c, c->wsum, J.P * 128))) return rc;
+
+  uint32_t* hist = (uint32_t*)c->hist.p; uint32_t* offs = (uint32_t*)c->offs.p;
+  uint32_t* sorted = (uint32_t*)c->sorted.p; uint32_t* buckets = (uint32_t*)c->buckets.p;
+  AccCounters* ctr = (AccCounters*)c->acc_ctr.p;
+
+  HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(AccCounters), c->stream));
+  // digits once, then the LDS counting sort
+  SortGeom g; memset(&g, 0, sizeof g);
+  g.E = estride; g.estride = estride; g.nb = s.nb; g.mode = J.mode; g.ncol = J.da.n; g.tstride = J.da.tstride;
+  g.RS = std::min(s.nb, c->sort_rs_max); g.logRS = 0; while ((1 << g.logRS) < g.RS) g.logRS++;
+  g.R = s.nb / g.RS;
+  { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
+  g.chunk = (estride + g.K - 1) / g.K;
+  if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
+  if ((rc = ensure(c, c->digits, J.P * estride * 4))) return rc;
+  if ((rc = ensure(c, c->blockhist, J.P * (size_t)g.R * g.K * g.RS * 4))) return rc;
+  int32_t* dig = (int32_t*)c->digits.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
+  const unsigned gd = (unsigned)((J.threads + 255) / 256);
+  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
+  else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
+  if (c->z_consumed && J.mode == MODE_ROWS) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));   // the scalars are not read again
+  const size_t rows_lds = sort_rows_lds_bytes(s.nb);
+  if (J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT")) {
+    ProfScope _ps(c, "k_sort_rows");
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const int32_t*)dig, g, hist, offs, sorted);
+  } else {
+    {
+      ProfScope _ps(c, "k_hist_lds");
+      hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, bh);
+    }
+    LAUNCH(c, "k_block_prefix", k_block_prefix, (unsigned)((NB + 255) / 256), 256, bh, g, NB, hist);
+    LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, s.nb);
+    {
+      ProfScope _ps(c, "k_scatter_lds");
+      hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
+    }
+  }
+  // bucket order by decreasing load
+  if ((rc = ensure(c, c->size_bins, (ACC_SEG_MAX + 2) * 4))) return rc;
+  if ((rc = ensure(c, c->perm, NB * 4))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->size_bins.p, 0, (ACC_SEG_MAX + 2) * 4, c->stream));
+  LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p);
+  LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
+  LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
+  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
+         (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
+  LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
+  LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
+  LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
+  uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
+  int G = chunks, logM = 6 + logL;
+  for (;;) {
+    int Gout = (G + 63) / 64;
+    int final = (Gout == 1);
+    LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    if (final) break;
+    std::swap(in, outb); G = Gout; logM += 6;
+  }
+  LAUNCHCHK(c);
+  return SBN_OK;
+}
+
+// MSM over device-resident canonical scalars and Montgomery affine bases -> canonical affine bytes on the host
+static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_bases, size_t n, uint8_t out_xy[64], int* out_is_inf) {
+  if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
+  if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
+  BucketJob J; memset(&J, 0, sizeof J);
+  J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
+  J.da.scalars = d_scal; J.da.n = n; J.da.estride = n;
+  int rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;
+  if ((rc = run_bucket_job(c, J))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, J.P * 128, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  // sum_w 2^(c w) S_w: the 254-doubling serial chain, on the host
+  const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
+  sbn_host::Pt total = sbn_host::combine_windows(S, J.s.W, J.s.c);
+  sbn_host::to_affine_bytes(total, out_xy, out_is_inf);
+  return SBN_OK;
+}
+
+// window table 2^(c w) * P_j of a generator set, built on first use for a given c and kept with the handle
+static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s, const uint32_t** out) {
+  auto it = b->tables.find(s.c);
+  if (it != b->tables.end()) { *out = (const uint32_t*)it->second; return SBN_OK; }
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  const size_t tot = npts * (size_t)s.W;
+  int rc;
+  if ((rc = ensure(c, c->gen_tmp, tot * 128))) return rc;
+  void* tab = nullptr;
+  hipError_t e = hipMalloc(&tab, tot * 64);
+  if (e != hipSuccess) return fail(c, SBN_ENOMEM, "hipMalloc window table (%zu B): %s", tot * 64, hipGetErrorString(e));
+  LAUNCH(c, "k_window_table", k_window_table, (unsigned)((npts + 63) / 64), 64, (const uint32_t*)b->d_pts, npts, s.c, s.W, (uint32_t*)c->gen_tmp.p);
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((tot + 63) / 64), 64, (const uint32_t*)c->gen_tmp.p, (uint32_t*)tab, (uint32_t*)nullptr, (uint8_t*)nullptr, tot);
+  LAUNCHCHK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  b->tables[s.c] = tab;
+  *out = (const uint32_t*)tab;
+  return SBN_OK;
+}
+
+// Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
+// launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
+static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf) {
+  if (L == 0) return SBN_OK;
+  if (b->uniq) {
+    // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
+    const size_t U = b->U; int rc;
+    if ((rc = ensure(c, c->merged, L * U * 32))) return rc;
+    uint32_t* m = (uint32_t*)c->merged.p;
+    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * U + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, m);
+    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, m);
+    if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
+    return commit_rows_launch(c, b->uniq, m, nullptr, L, U, d_xy, d_inf);
+  }
+  const size_t ncol = R + (dBl ? 1 : 0);
+  if (ncol == 0) { HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK; }
+  BucketJob J; memset(&J, 0, sizeof J);
+  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16); J.P = L; J.threads = L * ncol;
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  if ((size_t)J.s.W * npts > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: table index overflow");
+  int rc; const uint32_t* tab;
+  if ((rc = bases_window_table(c, b, J.s, &tab))) return rc;
+  J.points = tab;
+  J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
+  if ((rc = run_bucket_job(c, J))) return rc;
+  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
+  LAUNCHCHK(c);
+  return SBN_OK;
+}
+// Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
+static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+  if (L == 0) return SBN_OK;
+  int rc;
+  if ((rc = ensure(c, c->out_small, L * 65))) return rc;
+  if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
+  if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->pin, c->out_small.p, L * 65, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  memcpy(out_xy, c->pin, L * 64);
+  if (out_inf) memcpy(out_inf, (uint8_t*)c->pin + L * 64, L);
+  return SBN_OK;
+}
+
+static int stage_scalars(sbn_ctx* c, const uint8_t* host_scalars, size_t n, uint32_t flags, const uint32_t** d_out) {
+  int rc;
+  if ((rc = ensure(c, c->stage_scal, n * 32))) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->stage_scal.p, host_scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+  if (flags & SBN_SCALARS_MONT) {
+    if ((rc = ensure(c, c->scal_canon, n * 32))) return rc;
+    LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((n + 255) / 256), 256, (const uint32_t*)c->stage_scal.p, (uint32_t*)c->scal_canon.p, n);
+    *d_out = (const uint32_t*)c->scal_canon.p;
+  } else *d_out = (const uint32_t*)c->stage_scal.p;
+  return SBN_OK;
+}
+static int canon_scalars_dev(sbn_ctx* c, const void* d_scalars, size_t n, uint32_t flags, const uint32_t** d_out) {
+  if (flags & SBN_SCALARS_MONT) {
+    int rc; if ((rc = ensure(c, c->scal_canon, n * 32))) return rc;
+    LAUNCH(c, "k_scalars_from_mont", k_scalars_from_mont, (unsigned)((n + 255) / 256), 256, (const uint32_t*)d_scalars, (uint32_t*)c->scal_canon.p, n);
+    *d_out = (const uint32_t*)c->scal_canon.p;
+  } else *d_out = (const uint32_t*)d_scalars;
+  return SBN_OK;
+}
+
+// Detect equal bases (keys: one byte string per point, equal keys <=> equal points) and, when enough of them repeat, attach
+// the unique-point table + CSR column lists used by the commit path.
+static int bases_build_dedupe(sbn_ctx* c, sbn_bases* b, const std::vector<std::string>& keys) {
+  const size_t tot = keys.size();
+  std::unordered_map<std::string, uint32_t> idx;
+  std::vector<uint32_t> umap(tot);
+  std::vector<uint32_t> first_col;
+  for (size_t j = 0; j < tot; j++) {
+    auto it = idx.find(keys[j]);
+    if (it == idx.end()) { uint32_t u = (uint32_t)first_col.size(); idx.emplace(keys[j], u); first_col.push_back((uint32_t)j); umap[j] = u; }
+    else umap[j] = it->second;
+  }
+  const size_t U = first_col.size();
+  if (getenv("SBN_NO_DEDUPE") || U * 10 > tot * 9) return SBN_OK;         // < 10 % repeats: not worth the extra pass
+  std::vector<uint32_t> off(U + 1, 0), cols(tot), big;
+  for (size_t j = 0; j < tot; j++) off[umap[j] + 1]++;
+  for (size_t u = 0; u < U; u++) off[u + 1] += off[u];
+  { std::vector<uint32_t> cur(off.begin(), off.end() - 1); for (size_t j = 0; j < tot; j++) cols[cur[umap[j]]++] = (uint32_t)j; }
+  for (size_t u = 0; u < U; u++) if (off[u + 1] - off[u] > MERGE_BIG) big.push_back((uint32_t)u);
+  sbn_bases* q = new sbn_bases(); q->n = U; q->has_h = false;
+  hipError_t e = hipMalloc(&q->d_pts, U * 64);
+  if (e != hipSuccess) { delete q; return fail(c, SBN_ENOMEM, "hipMalloc unique bases: %s", hipGetErrorString(e)); }
+  for (size_t u = 0; u < U; u++)
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)q->d_pts + 64 * u, (const uint8_t*)b->d_pts + 64 * (size_t)first_col[u], 64, hipMemcpyDeviceToDevice, c->stream));
+  auto up = [&](void** dst, const std::vector<uint32_t>& v) -> int {
+    hipError_t e2 = hipMalloc(dst, std::max<size_t>(4, v.size() * 4)); if (e2 != hipSuccess) return SBN_ENOMEM;
+    if (!v.empty() && hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return SBN_EHIP;
+    return SBN_OK;
+  };
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = up(&b->d_csr_off, off)) || (rc = up(&b->d_csr_cols, cols)) || (rc = up(&b->d_big, big))) { sbn_bases_free(c, q); return fail(c, rc, "dedupe tables"); }
+  b->uniq = q; b->U = U; b->nbig = (uint32_t)big.size();
+  return SBN_OK;
+}

@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const int32_t* __restrict__ 
   }
 }
 
-// exclusive scan per problem: offs[p][b] = sum_{b'<b} hist[p][b'];  cursor = copy of offs.  One block per problem.
-__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor, int nb) {
+// exclusive scan per problem: offs[p][b] = sum_{b'<b} hist[p][b'].  One block per problem.
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, int nb) {
   __shared__ uint32_t part[1024];
   const size_t w = blockIdx.x; const int t = threadIdx.x, T = blockDim.x;
   const int per = (nb + T - 1) / T;
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* __restrict__ hist
   uint32_t run = part[t] - sum;
   for (int j = 0; j < per; j++) {
     int b = t * per + j;
-    if (b < nb) { offs[w * nb + b] = run; cursor[w * nb + b] = run; run += h[b]; }
+    if (b < nb) { offs[w * nb + b] = run; run += h[b]; }
   }
 }
 

@@ -30,7 +30,7 @@ def test_no_oracle_in_product():
     pk = os.path.join(ROOT, "spartan-bn254_amd")
     for dirpath, _, files in os.walk(pk):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".h", "Makefile")):
+            if f.endswith((".py", ".hip", ".cuh", ".hpp", ".inc", ".h", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "bn254_oracle" not in txt and "libsbn_oracle" not in txt and "orc_" not in txt, f
                 assert "oracle_lib" not in txt, f
