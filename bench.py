@@ -217,8 +217,8 @@ def main():
     pool = ThreadPoolExecutor(max_workers=M)
 
     def run_steps(count):
-        """`count` steps with up to M in flight.  N = 1: each stream free-runs its share.  N > 1: groups of M local steps,
-        then one collective per group issued from this thread (collectives must be ordered identically on every rank)."""
+        """`count` steps with up to M in flight.  N = 1: each stream free-runs its share.  N > 1: rounds of up to 4*M local steps,
+        then one collective per round issued from this thread (collectives must be ordered identically on every rank)."""
         if M == 1:
             for _ in range(count):
                 step()
@@ -230,10 +230,11 @@ def main():
                 f.result()
             return
         done = 0
-        while done < count:
-            g = min(M, count - done)
-            futs = [pool.submit(local_step, ctxs[j]) for j in range(g)]
-            finish([f.result() for f in futs])
+        while done < count:                       # rounds of up to 4 steps per stream, then ONE all-gather carrying all their partials
+            g = min(4 * M, count - done)
+            shares = [g // M + (1 if j < g % M else 0) for j in range(M)]
+            futs = [pool.submit(lambda cx=cx, k=k: [local_step(cx) for _ in range(k)]) for cx, k in zip(ctxs, shares) if k]
+            finish([p for f in futs for p in f.result()])
             done += g
 
     for cx in ctxs:                       # every stream's workspace is sized before the timed region
