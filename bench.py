@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=4, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
     ap.add_argument("--fixed-base", action="store_true", help="msm: treat the resident bases as fixed generators (per-window multiples precomputed once, "
                     "as the commit path does): sbn_commit_rows with L = 1 instead of sbn_msm_bases")
+    ap.add_argument("--const-tail", type=float, default=0.0, help="hyrax: fraction of each 512-row block whose rows repeat one constant "
+                    "(the padded tail of every derefs matrix repeats mem[0], sparse_mlpoly_full.rs:89-101; ~0.43 at keyless size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -189,6 +191,11 @@ def main():
         Z = torch.randint(0, 2**31 - 1, (L * Rc, 8), dtype=torch.int32, device=dev, generator=g)
         Z[:, 7] &= 0x0fffffff                                     # canonical (< 2^252)
         Z[(3 * L // 4) * Rc:] = 0                                  # rows 3072.. are zero padding (hyrax.rs:245)
+        if args.const_tail > 0:                                    # SURVEY 8d config 3 variant: constant suffix of every 512-row block
+            blk = max(1, L // 8)
+            for b0 in range(0, 3 * L // 4, blk):
+                k0 = b0 + int(blk * (1.0 - args.const_tail))
+                Z[k0 * Rc:(b0 + blk) * Rc] = Z[k0 * Rc]
         torch.cuda.synchronize()
 
         def local_step(cx):
@@ -209,7 +216,8 @@ def main():
         units_per_step = L * Rc
         alg_bytes_per_launch = L * Rc * 32.0 + (Rc + 1) * 64.0 + L * 64.0     # 32.02 B/pair at 4096 x 8192
         dominant = "k_acc_first"
-        workload = f"Hyrax derefs commitment shape: {L} x {Rc} scalars per GPU, {Rc}+1 shared reference generators, last quarter of rows zero, inputs resident in HBM"
+        workload = f"Hyrax derefs commitment shape: {L} x {Rc} scalars per GPU, {Rc}+1 shared reference generators, last quarter of rows zero, inputs resident in HBM" + (
+            f", constant tail {args.const_tail:.2f} of every {max(1, L // 8)}-row block" if args.const_tail > 0 else "")
         metric = "msm_points_per_s"
         unit = "points/s"
 

@@ -22,6 +22,7 @@ struct sbn_ctx {
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
+  std::vector<std::pair<void*, size_t>> pool; size_t pool_bytes = 0;   // cached table buffers (see pool_get)
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;
@@ -36,16 +37,44 @@ struct sbn_bases {
   mutable std::unordered_map<int, void*> tables;   // window bits c -> W x (n + has_h) x 64 B: 2^(c w) * P_j (built on first commit)
   // equal bases merged (commit path): unique points as their own table + CSR of the columns that map to each
   sbn_bases* uniq = nullptr;
-  size_t U = 0; uint32_t nbig = 0;
+  size_t U = 0; uint32_t nbig = 0; uint32_t hcol = 0;   // hcol: the unique base h maps to
   void* d_csr_off = nullptr; void* d_csr_cols = nullptr; void* d_big = nullptr;
 };
 static const uint32_t MERGE_BIG = 64;
 extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);
 
 struct sbn_table {
-  void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;
+  void* d = nullptr; size_t len = 0; size_t cap = 0; bool owned = true;      // cap / cap2: capacity in 32-byte elements
   void* d2 = nullptr; size_t cap2 = 0; bool owned2 = true;     // second buffer for the fused (out-of-place) bind
 };
+
+// Table buffers come from a small per-context cache: hipMalloc / hipFree of a 1 GiB buffer costs tens of milliseconds (it
+// synchronises the device and maps / unmaps pages), more than the kernels that fill it, and a prover allocates the same
+// shapes every round.  pool_get returns a cached buffer of at least `bytes` (best fit) or allocates; pool_put keeps up to
+// POOL_MAX_ENTRIES buffers / POOL_MAX_BYTES and releases the rest.
+static const size_t POOL_MAX_ENTRIES = 96;
+static const size_t POOL_MAX_BYTES = (size_t)24 << 30;
+static hipError_t pool_get(sbn_ctx* c, size_t bytes, void** out, size_t* got_bytes) {
+  if (bytes == 0) bytes = 32;
+  int best = -1;
+  for (size_t i = 0; i < c->pool.size(); i++)
+    if (c->pool[i].second >= bytes && c->pool[i].second <= 2 * bytes && (best < 0 || c->pool[i].second < c->pool[(size_t)best].second)) best = (int)i;
+  if (best >= 0) { *out = c->pool[(size_t)best].first; *got_bytes = c->pool[(size_t)best].second; c->pool_bytes -= *got_bytes; c->pool.erase(c->pool.begin() + best); return hipSuccess; }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && !c->pool.empty()) {          // out of memory: drop the cache and retry once
+    (void)hipGetLastError();
+    for (auto& b : c->pool) hipFree(b.first);
+    c->pool.clear(); c->pool_bytes = 0;
+    e = hipMalloc(out, bytes);
+  }
+  *got_bytes = bytes;
+  return e;
+}
+static void pool_put(sbn_ctx* c, void* p, size_t bytes) {
+  if (!p) return;
+  if (!c || c->pool.size() >= POOL_MAX_ENTRIES || c->pool_bytes + bytes > POOL_MAX_BYTES) { hipFree(p); return; }
+  c->pool.emplace_back(p, bytes); c->pool_bytes += bytes;
+}
 
 static int fail(sbn_ctx* c, int code, const char* fmt, ...) {
   char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);

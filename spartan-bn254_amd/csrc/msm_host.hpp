@@ -118,7 +118,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p);
   LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
   LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
-  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + 255) / 256), 256, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
+  unsigned ab = 256; if (const char* eb = getenv("SBN_ACC_BLOCK")) { int v = atoi(eb); if (v == 64 || v == 128 || v == 256) ab = (unsigned)v; }
+  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + ab - 1) / ab), ab, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
          (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
   LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
@@ -184,12 +185,14 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   if (b->uniq) {
     // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
     const size_t U = b->U; int rc;
-    if ((rc = ensure(c, c->merged, L * U * 32))) return rc;
-    uint32_t* m = (uint32_t*)c->merged.p;
-    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * U + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, m);
-    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, m);
+    if ((rc = ensure(c, c->merged, L * (U + 1) * 32 + L))) return rc;
+    uint32_t* m = (uint32_t*)c->merged.p; uint8_t* rowflags = (uint8_t*)c->merged.p + L * (U + 1) * 32;
+    if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, R, rowflags);
+    else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
+    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
+    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
-    return commit_rows_launch(c, b->uniq, m, nullptr, L, U, d_xy, d_inf);
+    return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf);
   }
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) { HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK; }
@@ -260,8 +263,9 @@ static int bases_build_dedupe(sbn_ctx* c, sbn_bases* b, const std::vector<std::s
   for (size_t u = 0; u < U; u++) off[u + 1] += off[u];
   { std::vector<uint32_t> cur(off.begin(), off.end() - 1); for (size_t j = 0; j < tot; j++) cols[cur[umap[j]]++] = (uint32_t)j; }
   for (size_t u = 0; u < U; u++) if (off[u + 1] - off[u] > MERGE_BIG) big.push_back((uint32_t)u);
-  sbn_bases* q = new sbn_bases(); q->n = U; q->has_h = false;
-  hipError_t e = hipMalloc(&q->d_pts, U * 64);
+  // the unique table carries one extra point: S = sum of the n bases (h excluded), the base of constant rows
+  sbn_bases* q = new sbn_bases(); q->n = U + 1; q->has_h = false;
+  hipError_t e = hipMalloc(&q->d_pts, (U + 1) * 64);
   if (e != hipSuccess) { delete q; return fail(c, SBN_ENOMEM, "hipMalloc unique bases: %s", hipGetErrorString(e)); }
   for (size_t u = 0; u < U; u++)
     HIPCHK(c, hipMemcpyAsync((uint8_t*)q->d_pts + 64 * u, (const uint8_t*)b->d_pts + 64 * (size_t)first_col[u], 64, hipMemcpyDeviceToDevice, c->stream));
@@ -274,5 +278,21 @@ static int bases_build_dedupe(sbn_ctx* c, sbn_bases* b, const std::vector<std::s
   int rc;
   if ((rc = up(&b->d_csr_off, off)) || (rc = up(&b->d_csr_cols, cols)) || (rc = up(&b->d_big, big))) { sbn_bases_free(c, q); return fail(c, rc, "dedupe tables"); }
   b->uniq = q; b->U = U; b->nbig = (uint32_t)big.size();
+  b->hcol = (b->has_h) ? umap[tot - 1] : (uint32_t)(U + 1);
+  // S = sum_u mult_u * U_u with mult_u = number of G columns (index < n) that map to u: a U-term MSM with tiny scalars
+  {
+    const size_t n = b->n;
+    std::vector<uint8_t> mult(U * 32, 0);
+    for (size_t j = 0; j < n; j++) { uint32_t* m = (uint32_t*)&mult[32 * umap[j]]; m[0] += 1; }
+    int rc2;
+    if ((rc2 = ensure(c, c->stage_scal, U * 32))) return rc2;
+    HIPCHK(c, hipMemcpyAsync(c->stage_scal.p, mult.data(), U * 32, hipMemcpyHostToDevice, c->stream));
+    uint8_t sxy[64]; int sinf = 0;
+    if ((rc2 = msm_device(c, (const uint32_t*)c->stage_scal.p, (const uint32_t*)q->d_pts, U, sxy, &sinf))) return rc2;
+    sbn_host::Fq x, y; memcpy(x.v, sxy, 32); memcpy(y.v, sxy + 32, 32);
+    uint8_t sm[64]; memset(sm, 0, 64);
+    if (!sinf) { sbn_host::Fq xm = sbn_host::to_mont(x), ym = sbn_host::to_mont(y); memcpy(sm, xm.v, 32); memcpy(sm + 32, ym.v, 32); }
+    HIPCHK(c, hipMemcpy((uint8_t*)q->d_pts + 64 * U, sm, 64, hipMemcpyHostToDevice));
+  }
   return SBN_OK;
 }

@@ -518,24 +518,46 @@ __device__ __forceinline__ Fr merged_load(const uint32_t* __restrict__ Z, const 
   if (blinds) return fe_load<FrP>(blinds + 8 * row);
   return fe_zero<FrP>();
 }
-// small groups: one lane per (row, unique base)
+// Rows whose R scalars are all equal (the padded tail of every derefs matrix repeats mem[0]: sparse_mlpoly_full.rs:89-101,
+// ~43 % of the non-zero rows at keyless size) commit to v * (sum_j G_j): the unique-base table carries that sum as one
+// extra column, the row's value goes there and every other merged scalar of the row is zero (only h keeps the blind).
+// flags[row] = 1 when the row is constant.  One block per row.
+__global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restrict__ Z, size_t R, uint8_t* __restrict__ flags) {
+  const size_t row = blockIdx.x;
+  const uint4* z = reinterpret_cast<const uint4*>(Z + 8 * row * R);
+  const uint4 a0 = z[0], a1 = z[1];
+  int diff = 0;
+  for (size_t j = threadIdx.x; j < R; j += blockDim.x) {
+    const uint4 b0 = z[2 * j], b1 = z[2 * j + 1];
+    diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
+  }
+  const int any = __syncthreads_or(diff != 0);
+  if (threadIdx.x == 0) flags[row] = any ? 0 : 1;
+}
+// small groups: one lane per (row, merged column).  Column U is the sum-of-all-bases column; hcol = the unique base h maps to
+// (or U+1 when the table has no h).
 __global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
                                                      const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
-                                                     uint32_t* __restrict__ out) {
+                                                     const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= L * U) return;
-  const size_t row = t / U, u = t - row * U;
+  const size_t W1 = U + 1;
+  if (t >= L * W1) return;
+  const size_t row = t / W1, u = t - row * W1;
+  const bool cst = flags[row] != 0;
+  if (u == U) { fe_store<FrP>(out + 8 * t, cst ? fe_load<FrP>(Z + 8 * row * R) : fe_zero<FrP>()); return; }
+  if (cst) { fe_store<FrP>(out + 8 * t, (u == hcol && blinds) ? fe_load<FrP>(blinds + 8 * row) : fe_zero<FrP>()); return; }
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   if (b - a > big_threshold) return;                     // k_merge_big owns it
   Fr acc = merged_load(Z, blinds, row, R, csr_cols[a]);
   for (uint32_t j = a + 1; j < b; j++) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
   fe_store<FrP>(out + 8 * t, acc);
 }
-// big groups: one wave per (row, big group)
+// big groups: one wave per (row, big group); constant rows were written by k_merge_small
 __global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
                                                   const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
-                                                  const uint32_t* __restrict__ big_list, uint32_t nbig, uint32_t* __restrict__ out) {
+                                                  const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
   const size_t row = blockIdx.x / nbig; const uint32_t u = big_list[blockIdx.x % nbig];
+  if (flags[row]) return;
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   Fr acc = fe_zero<FrP>();
   for (uint32_t j = a + threadIdx.x; j < b; j += 64) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
@@ -547,7 +569,7 @@ __global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z
     for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(acc.v[i], d, 64);
     acc = fe_add(acc, o);
   }
-  if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * U + u), acc);
+  if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * (U + 1) + u), acc);
 }
 
 // Jacobian (X, Y, Z) -> Montgomery affine, one lane per point (x = X/Z^2, y = Y/Z^3); canonical input is converted first
