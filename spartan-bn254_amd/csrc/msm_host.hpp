@@ -159,7 +159,11 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
 }
 
 // window table 2^(c w) * P_j of a generator set, built on first use for a given c and kept with the handle
+// A generator set may be shared by several contexts (one per host thread / stream); its lazily built tables are guarded by
+// one process-wide mutex (taken after the context's own, never the other way round).
+static std::mutex g_bases_tables_mu;
 static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s, const uint32_t** out) {
+  std::lock_guard<std::mutex> tg(g_bases_tables_mu);
   auto it = b->tables.find(s.c);
   if (it != b->tables.end()) { *out = (const uint32_t*)it->second; return SBN_OK; }
   const size_t npts = b->n + (b->has_h ? 1 : 0);

@@ -228,6 +228,25 @@ def test_two_contexts_concurrently(sbn, ol, pr):
     b.free(); c1.close(); c2.close()
 
 
+def test_shared_generators_first_commit_from_two_threads(sbn, ol):
+    """two contexts commit against ONE freshly created generator set at the same time: the lazily built window table of the
+    set must be built once and seen by both"""
+    import threading
+    R, L = 512, 6
+    c1, c2 = sbn.Context(0), sbn.Context(0)
+    b, gxy = c1.gens_new(R, b"gens_r1cs_sat")
+    Z1, Z2 = rand_scalars(L * R, 70), rand_scalars(L * R, 71)
+    got = {}
+
+    def work(name, cx, Z):
+        got[name] = cx.commit_rows(b, Z, None, L, R)[0]
+    t1 = threading.Thread(target=work, args=("a", c1, Z1)); t2 = threading.Thread(target=work, args=("b", c2, Z2))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert got["a"] == ol.commit_rows(Z1, None, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    assert got["b"] == ol.commit_rows(Z2, None, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    b.free(); c1.close(); c2.close()
+
+
 def test_commit_argument_errors(ctx, ol, sbn):
     gx, _ = ol.gens_new(8, b"x")
     b = ctx.bases_upload(gx[:64 * 8], gx[64 * 8:])
