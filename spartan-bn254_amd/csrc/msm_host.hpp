@@ -19,10 +19,11 @@ static MsmShape make_shape(int c) {
 // SBN_MSM_C overrides for experiments.
 static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax) {
   const char* env = getenv("SBN_MSM_C");
-  if (env && atoi(env) >= 7 && atoi(env) <= 22) return make_shape(atoi(env));
+  if (env && atoi(env) >= 7 && atoi(env) <= MSM_C_MAX) return make_shape(atoi(env));
   double best = 1e300; int bc = 7;
   // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
   // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows.
+  if (cmax > MSM_C_MAX) cmax = MSM_C_MAX;
   for (int c = 7; c <= cmax; c++) {
     MsmShape s = make_shape(c);
     double sets = shared_bucket_set ? 1.0 : (double)s.W;
@@ -88,9 +89,9 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
   g.chunk = (estride + g.K - 1) / g.K;
   if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
-  if ((rc = ensure(c, c->digits, J.P * estride * 4))) return rc;
+  if ((rc = ensure(c, c->digits, J.P * estride * sizeof(dig_t)))) return rc;
   if ((rc = ensure(c, c->blockhist, J.P * (size_t)g.R * g.K * g.RS * 4))) return rc;
-  int32_t* dig = (int32_t*)c->digits.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
+  dig_t* dig = (dig_t*)c->digits.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
   if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
   else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
@@ -98,17 +99,17 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const size_t rows_lds = sort_rows_lds_bytes(s.nb);
   if (J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT")) {
     ProfScope _ps(c, "k_sort_rows");
-    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const int32_t*)dig, g, hist, offs, sorted);
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const dig_t*)dig, g, hist, offs, sorted);
   } else {
     {
       ProfScope _ps(c, "k_hist_lds");
-      hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, bh);
+      hipLaunchKernelGGL(k_hist_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const dig_t*)dig, g, bh);
     }
     LAUNCH(c, "k_block_prefix", k_block_prefix, (unsigned)((NB + 255) / 256), 256, bh, g, NB, hist);
     LAUNCH(c, "k_scan", k_scan, (unsigned)J.P, 1024, hist, offs, s.nb);
     {
       ProfScope _ps(c, "k_scatter_lds");
-      hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const int32_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
+      hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const dig_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
     }
   }
   // bucket order by decreasing load

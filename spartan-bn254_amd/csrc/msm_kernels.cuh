@@ -73,10 +73,13 @@ struct DigitArgs {
   size_t estride;            // sorted-entry capacity per problem
 };
 
-// signed digits of every scalar, stored once (int32): dig[p*E + e]
+// signed digits of every scalar, stored once: dig[p*E + e].  Window bits never exceed 16 (LDS counter capacity), so a
+// digit in [-2^15, 2^15) fits 16 bits: half the bytes of the three passes that stream the digit array.
+typedef int16_t dig_t;
+constexpr int MSM_C_MAX = 16;
 //   SINGLE: p = window w, e = scalar index          ROWS: p = row, e = w*ncol + col
 template <int MODE>
-__global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, int32_t* __restrict__ dig) {
+__global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, dig_t* __restrict__ dig) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* k; size_t row = 0, col = 0;
   if (MODE == MODE_SINGLE) {
@@ -90,8 +93,8 @@ __global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, i
   uint32_t carry = 0;
   for (int w = 0; w < s.W; w++) {
     const int d = window_digit(k, w, s.c, carry);
-    if (MODE == MODE_SINGLE) dig[(size_t)w * a.n + t] = d;
-    else dig[row * a.estride + (size_t)w * a.n + col] = d;
+    if (MODE == MODE_SINGLE) dig[(size_t)w * a.n + t] = (dig_t)d;
+    else dig[row * a.estride + (size_t)w * a.n + col] = (dig_t)d;
   }
 }
 
@@ -110,12 +113,12 @@ struct SortGeom {
 };
 extern __shared__ uint32_t sort_lds[];
 
-__global__ void __launch_bounds__(1024) k_hist_lds(const int32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blockhist) {
+__global__ void __launch_bounds__(1024) k_hist_lds(const dig_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blockhist) {
   const int k = blockIdx.x, r = blockIdx.y; const size_t p = blockIdx.z;
   for (int j = threadIdx.x; j < g.RS; j += blockDim.x) sort_lds[j] = 0;
   __syncthreads();
   const size_t e0 = (size_t)k * g.chunk, e1 = (e0 + g.chunk < g.E) ? e0 + g.chunk : g.E;
-  const int32_t* d = dig + p * g.E;
+  const dig_t* d = dig + p * g.E;
   for (size_t e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
     const int v = d[e];
     if (v == 0) continue;
@@ -137,13 +140,13 @@ __global__ void __launch_bounds__(256) k_block_prefix(uint32_t* __restrict__ blo
   for (int k = 0; k < g.K; k++) { const uint32_t v = q[(size_t)k * g.RS]; q[(size_t)k * g.RS] = run; run += v; }
   hist[t] = run;
 }
-__global__ void __launch_bounds__(1024) k_scatter_lds(const int32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+__global__ void __launch_bounds__(1024) k_scatter_lds(const dig_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blockhist, const uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
   const int k = blockIdx.x, r = blockIdx.y; const size_t p = blockIdx.z;
   const uint32_t* base = blockhist + ((p * g.R + r) * g.K + k) * (size_t)g.RS;
   const uint32_t* off = offs + p * g.nb + (size_t)r * g.RS;
   for (int j = threadIdx.x; j < g.RS; j += blockDim.x) sort_lds[j] = off[j] + base[j];
   __syncthreads();
-  const int32_t* d = dig + p * g.E;
+  const dig_t* d = dig + p * g.E;
   uint32_t* out = sorted + p * g.estride;
   if (g.mode == MODE_SINGLE) {
     const size_t e0 = (size_t)k * g.chunk, e1 = (e0 + g.chunk < g.E) ? e0 + g.chunk : g.E;
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(1024) k_scatter_lds(const int32_t* __restrict_
 // entries (by the start offset of their bucket), each range is assembled in LDS and flushed with coalesced stores.
 constexpr uint32_t SORT_SL_LOG = 15, SORT_SL = 1u << SORT_SL_LOG, SORT_SLACK = 1024, SORT_MAXR = 64;
 __host__ __device__ inline size_t sort_rows_lds_bytes(int nb) { return ((size_t)nb + (size_t)nb / 4 + 1024 + SORT_MAXR + 2 + SORT_SL + SORT_SLACK) * 4; }
-__global__ void __launch_bounds__(1024) k_sort_rows(const int32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+__global__ void __launch_bounds__(1024) k_sort_rows(const dig_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
   uint32_t* cnt = sort_lds;                                     // nb counters, then cursors
   uint8_t* rng = reinterpret_cast<uint8_t*>(sort_lds + g.nb);   // range id of every bucket (start offset >> SORT_SL_LOG; the host keeps E <= 8*SORT_SL)
   uint32_t* part = sort_lds + g.nb + g.nb / 4;                  // 1024 scan partials
@@ -186,7 +189,7 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const int32_t* __restrict__ 
   const size_t p = blockIdx.x;
   const int t = threadIdx.x, T = blockDim.x;
   const uint32_t ncol = (uint32_t)g.ncol, W = (uint32_t)(g.E / g.ncol);
-  const int32_t* d = dig + p * g.E;
+  const dig_t* d = dig + p * g.E;
   uint32_t* out = sorted + p * g.estride;
   for (int j = t; j < g.nb; j += T) cnt[j] = 0;
   __syncthreads();
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(1024) k_sort_rows(const int32_t* __restrict__ 
     const uint32_t r0 = r << SORT_SL_LOG;
     const uint8_t rtag = (uint8_t)(r < 255 ? r : 255);
     for (uint32_t w = 0; w < W; w++) {
-      const int32_t* dw = d + (size_t)w * ncol;
+      const dig_t* dw = d + (size_t)w * ncol;
       const uint32_t tb = w * (uint32_t)g.tstride;
       for (uint32_t col = t; col < ncol; col += T) {
         const int v = dw[col];
