@@ -247,6 +247,65 @@ def test_shared_generators_first_commit_from_two_threads(sbn, ol):
     b.free(); c1.close(); c2.close()
 
 
+def test_fuzz_random_shapes(ctx, ol, pr, sbn):
+    """seeded fuzz over shapes / flags / degenerate patterns, every result against the oracle: ragged sizes around the internal
+    thresholds (64-bucket chunks, 32-term window rule, LDS ranges), duplicated and opposite bases, zero / tiny / r-1 scalars,
+    Montgomery-form inputs, blinds on and off."""
+    import random
+    rnd = random.Random(20260404)
+    G = pr.point_to_xy(pr.G)
+    pool_dl = rand_scalars(600, 555)
+    pool_pts = ol.g1_mul_gen_batch(pool_dl, 16)
+    rr = ((1 << 256) % pr.R).to_bytes(32, "little")
+
+    def pick_scalar():
+        m = rnd.randrange(8)
+        if m == 0:
+            return 0
+        if m == 1:
+            return rnd.randrange(1, 16)
+        if m == 2:
+            return pr.R - 1 - rnd.randrange(4)
+        if m == 3:
+            return 1 << rnd.randrange(1, 253)
+        return rnd.randrange(pr.R)
+
+    for it in range(40):
+        n = rnd.choice([1, 2, 31, 32, 33, 63, 64, 65, 127, 200, 513, rnd.randrange(1, 600)])
+        idx = [rnd.randrange(600) if rnd.random() < 0.7 else rnd.randrange(8) for _ in range(n)]      # many repeated bases
+        pts = bytearray(); dls = []
+        for i in idx:
+            p = pool_pts[64 * i:64 * i + 64]; d = int.from_bytes(pool_dl[32 * i:32 * i + 32], "little")
+            if rnd.random() < 0.15:
+                p = ol.g1_neg(p); d = (-d) % pr.R
+            if rnd.random() < 0.03:
+                p = bytes(64); d = 0                                                                   # a base at infinity
+            pts += p; dls.append(d)
+        ks = [pick_scalar() for _ in range(n)]
+        kb = b"".join(k.to_bytes(32, "little") for k in ks)
+        want = ol.g1_mul(G, (sum(k * d for k, d in zip(ks, dls)) % pr.R).to_bytes(32, "little"))
+        flags = 0
+        if rnd.random() < 0.3:
+            kb = b"".join(ol.fe_op("mul", 1, kb[32 * i:32 * i + 32], rr) for i in range(n)); flags |= sbn.SBN_SCALARS_MONT
+        out, inf = ctx.msm(kb, bytes(pts), flags)
+        assert out == want, (it, n)
+        assert inf == (want == bytes(64))
+    for it in range(25):
+        L = rnd.choice([1, 2, 3, 5, 17]); R = rnd.choice([1, 2, 7, 64, 65, 300, rnd.randrange(1, 400)])
+        label = rnd.choice([b"gens_r1cs_eval", b"gens_r1cs_sat", b"fuzz%d" % it])
+        gx, _ = ol.gens_new(R, label)
+        Z = bytearray(b"".join(pick_scalar().to_bytes(32, "little") for _ in range(L * R)))
+        if L > 1 and rnd.random() < 0.5:
+            row = rnd.randrange(L); Z[32 * R * row:32 * R * (row + 1)] = Z[32 * R * row:32 * R * row + 32] * R   # constant row
+        Z = bytes(Z)
+        bl = rand_scalars(L, 900 + it) if rnd.random() < 0.5 else None
+        with_h = bl is not None or rnd.random() < 0.5
+        b = ctx.bases_upload(gx[:64 * R], gx[64 * R:] if with_h else None)
+        got = ctx.commit_rows(b, Z, bl, L, R)[0]
+        b.free()
+        assert got == ol.commit_rows(Z, bl, L, R, gx[:64 * R], gx[64 * R:], 8), (it, L, R, label)
+
+
 def test_commit_argument_errors(ctx, ol, sbn):
     gx, _ = ol.gens_new(8, b"x")
     b = ctx.bases_upload(gx[:64 * 8], gx[64 * 8:])
