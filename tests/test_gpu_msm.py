@@ -408,6 +408,37 @@ def test_full_size_properties_2p20(ctx, ol, pr):
         b.free()
 
 
+def _dot_arith(pr, scalars, first, n):
+    """sum_i k_i * (S0 + (first+i)*DSTEP) mod r, vectorised on 16-bit digits so every numpy partial sum stays below 2^64"""
+    k16 = np.frombuffer(scalars, dtype=np.uint16).reshape(n, 16).astype(np.uint64)
+    idx = np.arange(n, dtype=np.uint64)
+    ilo, ihi = idx & np.uint64(0xFFFF), idx >> np.uint64(16)
+    sum_k = 0; sum_ik = 0
+    for j in range(16):
+        col = k16[:, j]
+        sum_k += int(col.sum(dtype=np.uint64)) << (16 * j)
+        sum_ik += (int((col * ilo).sum(dtype=np.uint64)) + (int((col * ihi).sum(dtype=np.uint64)) << 16)) << (16 * j)
+    return ((S0 * sum_k + DSTEP * (sum_ik + first * sum_k)) % pr.R).to_bytes(32, "little")
+
+
+@pytest.mark.parametrize("logn", [22, 23])
+def test_large_msm_dlog_identity(ctx, ol, pr, logn):
+    """upper part of the BASELINE size range (2^23 = one GPU's share of config 4, 2^26 over 8 GPUs): window bits at the
+    16-bit cap, many chunks per window, long bucket chains; checked exactly through the discrete-log identity"""
+    import torch
+    n = 1 << logn
+    first = 12345
+    b = ctx.bases_synthetic(n, first, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    try:
+        k = _dev_scalars(torch, n, logn)
+        torch.cuda.synchronize()
+        out, inf = ctx.msm_bases_dev(b, k.data_ptr(), n)
+        kb = k.cpu().numpy().tobytes()
+        assert out == ol.g1_mul(pr.point_to_xy(pr.G), _dot_arith(pr, kb, first, n)) and not inf
+    finally:
+        b.free()
+
+
 def test_hyrax_derefs_shape_properties(ctx, ol, pr):
     """BASELINE config 3: the derefs commitment shape 4096 x 8192 over the reference's generator set, rows
     3072.. zero (hyrax.rs:245).  Checked on sampled rows against single-row commits of the oracle + structure."""
