@@ -106,6 +106,10 @@ int sbn_g1_compress(const uint8_t* xy, size_t n, uint8_t* out32);
 /* sum of n canonical affine points on the host (no device needed): the fold of per-GPU partial MSM results after
  * the RCCL all-gather, i.e. the `+` of GroupElement (group.rs:199-262) applied n-1 times */
 int sbn_g1_sum(const uint8_t* xy, size_t n, uint8_t out_xy[64], int* out_is_inf);
+/* UniPoly::from_evals (unipoly.rs:28-59): the round polynomial from its values at 0, 1, 2[, 3] (n = 3 or 4 canonical scalars,
+ * in the order [e0, claim - e0, e2, e3] of sumcheck.rs:137); coeffs low..high.  Host only.  UniPoly::evaluate (unipoly.rs:74-82). */
+int sbn_unipoly_from_evals(const uint8_t* evals, size_t n, uint8_t* coeffs);
+int sbn_unipoly_eval(const uint8_t* coeffs, size_t n, const uint8_t r[32], uint8_t out[32]);
 /* EqPolynomial::compute_factored_lens (hyrax.rs:371-373) */
 void sbn_factored_lens(size_t ell, size_t* left, size_t* right);
 

@@ -6,5 +6,5 @@ gfx950 device is missing, loading / context creation raises.
 """
 from .binding import (  # noqa: F401
     Context, Bases, Table, SbnError, lib, lib_path, build_library,
-    SBN_SCALARS_MONT, SBN_POINTS_MONT, g1_compress, g1_sum, factored_lens, EXPORTED_SYMBOLS,
+    SBN_SCALARS_MONT, SBN_POINTS_MONT, g1_compress, g1_sum, unipoly_from_evals, unipoly_eval, factored_lens, EXPORTED_SYMBOLS,
 )

@@ -11,7 +11,7 @@ EXPORTED_SYMBOLS = [
     "sbn_ctx_create", "sbn_ctx_destroy", "sbn_last_error", "sbn_ctx_set_stream", "sbn_ctx_sync", "sbn_version",
     "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
     "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_bases_download",
-    "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_factored_lens",
+    "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_unipoly_from_evals", "sbn_unipoly_eval", "sbn_factored_lens",
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
@@ -92,6 +92,23 @@ def g1_sum(xy):
     if rc:
         raise SbnError(f"sbn_g1_sum rc={rc}")
     return bytes(out), bool(inf.value)
+
+
+def unipoly_from_evals(evals):
+    """UniPoly::from_evals (unipoly.rs:28-59), host side"""
+    n = len(evals) // 32; out = (C.c_uint8 * (32 * n))()
+    rc = lib().sbn_unipoly_from_evals(_ptr(evals), C.c_size_t(n), out)
+    if rc:
+        raise SbnError(f"sbn_unipoly_from_evals rc={rc}")
+    return bytes(out)
+
+
+def unipoly_eval(coeffs, r):
+    out = (C.c_uint8 * 32)()
+    rc = lib().sbn_unipoly_eval(_ptr(coeffs), C.c_size_t(len(coeffs) // 32), _ptr(r), out)
+    if rc:
+        raise SbnError(f"sbn_unipoly_eval rc={rc}")
+    return bytes(out)
 
 
 def factored_lens(ell):

@@ -110,4 +110,39 @@ static inline Pt combine_windows(const Pt* S, int W, int c) {
   return acc;
 }
 
+// ---- Fr (scalar field) on the host: only what UniPoly::from_evals / evaluate need (unipoly.rs:28-82) -----------------
+namespace fr {
+static const uint64_t P[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+static inline bool geq(const uint64_t a[4]) { for (int i = 3; i >= 0; i--) { if (a[i] > P[i]) return true; if (a[i] < P[i]) return false; } return true; }
+struct El { uint64_t v[4]; };                      // canonical integers (no Montgomery form: a handful of operations per round)
+static inline El add(const El& a, const El& b) {
+  El r; uint64_t c = 0;
+  for (int i = 0; i < 4; i++) { u128 s = (u128)a.v[i] + b.v[i] + c; r.v[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+  if (c || geq(r.v)) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r.v[i] - P[i] - br; r.v[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } }
+  return r;
+}
+static inline El sub(const El& a, const El& b) {
+  El r; uint64_t br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)a.v[i] - b.v[i] - br; r.v[i] = (uint64_t)d; br = (uint64_t)(d >> 127); }
+  if (br) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)r.v[i] + P[i] + c; r.v[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+  return r;
+}
+// a*b mod r by shift-and-add over the bits of b (256 modular doublings: fine for 3-4 values per sumcheck round)
+static inline El mul(const El& a, const El& b) {
+  El acc = {{0, 0, 0, 0}};
+  for (int i = 255; i >= 0; i--) { acc = add(acc, acc); if ((b.v[i >> 6] >> (i & 63)) & 1) acc = add(acc, a); }
+  return acc;
+}
+static inline El from_u64(uint64_t x) { El r = {{x, 0, 0, 0}}; return r; }
+static inline El inv_small(uint64_t k) {           // 1/k for k in {2, 6}: (r*m + 1)/k with the m that makes it divisible
+  // r = 1 mod 2 and r = 1 mod 6 (r - 1 is divisible by 2^28 * 3), so (r*(k-1) + 1) / k is an integer < r and k times it is 1 mod r
+  u128 carry = 1; uint64_t t[5];
+  for (int i = 0; i < 4; i++) { u128 s = (u128)P[i] * (k - 1) + carry; t[i] = (uint64_t)s; carry = s >> 64; }
+  t[4] = (uint64_t)carry;
+  El q; u128 rem = 0;
+  for (int i = 4; i >= 0; i--) { u128 cur = (rem << 64) | t[i]; uint64_t d = (uint64_t)(cur / k); rem = cur % k; if (i < 4) q.v[i] = d; }
+  return q;
+}
+}  // namespace fr
+
 }  // namespace sbn_host

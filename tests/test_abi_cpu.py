@@ -74,6 +74,33 @@ def test_g1_sum_host(sbn, ol, pr):
         sbn.g1_sum(b"\xff" * 64)          # non-canonical coordinates are rejected
 
 
+def test_unipoly_host_mirror(sbn, ol, pr):
+    """UniPoly::from_evals / evaluate (unipoly.rs:28-82) in the product's host code: the reference's own known answers
+    (unipoly.rs:130-184: 2x^2+3x+1 from (1,6,15); x^3+2x^2+3x+1 from (1,7,23,55)) and random values against the oracle"""
+    from conftest import fr_bytes, rand_scalars
+    for u in golden("sumcheck_kat.json")["unipoly"]:
+        ev = b"".join(H(x) for x in u["evals"])
+        co = sbn.unipoly_from_evals(ev)
+        assert co == b"".join(H(x) for x in u["coeffs"]), u["note"]
+        assert sbn.unipoly_eval(co, H(u["at"])) == H(u["value"])
+    assert sbn.unipoly_from_evals(fr_bytes([1, 6, 15])) == fr_bytes([1, 3, 2])
+    assert sbn.unipoly_from_evals(fr_bytes([1, 7, 23, 55])) == fr_bytes([1, 3, 2, 1])
+    for n in (3, 4):
+        for seed in range(10):
+            ev = rand_scalars(n, 100 * n + seed); r = rand_scalars(1, seed)
+            co = sbn.unipoly_from_evals(ev)
+            assert co == ol.unipoly_from_evals(ev)
+            assert sbn.unipoly_eval(co, r) == ol.unipoly_eval(co, r)
+            # p(0) + p(1) == e0 + e1 (the verifier's check, sumcheck.rs:62-66)
+            cs = [int.from_bytes(co[32 * i:32 * i + 32], "little") for i in range(n)]
+            e = [int.from_bytes(ev[32 * i:32 * i + 32], "little") for i in range(2)]
+            assert (cs[0] + sum(cs)) % pr.R == (e[0] + e[1]) % pr.R
+    with pytest.raises(sbn.SbnError):
+        sbn.unipoly_from_evals(rand_scalars(2, 1))
+    with pytest.raises(sbn.SbnError):
+        sbn.unipoly_from_evals(pr.R.to_bytes(32, "little") * 3)
+
+
 def test_device_entry_points_fail_loudly_without_gpu(sbn):
     import torch
     if torch.cuda.is_available():
