@@ -38,6 +38,7 @@ struct BucketJob {
   size_t P;               // problems (windows or rows)
   size_t threads;         // digit-kernel threads
   const uint32_t* points; // Montgomery affine points the entries index
+  const uint8_t* skip;    // ROWS: per-row flags, 2 = all-zero row whose stages can be skipped (or null)
 };
 
 // digits -> counting sort -> segmented bucket accumulation -> per-problem weighted sums in c->wsum (P x XYZZ)
@@ -93,13 +94,15 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if ((rc = ensure(c, c->blockhist, J.P * (size_t)g.R * g.K * g.RS * 4))) return rc;
   dig_t* dig = (dig_t*)c->digits.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
-  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig);
-  else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig);
-  if (c->z_consumed && J.mode == MODE_ROWS) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));   // the scalars are not read again
   const size_t rows_lds = sort_rows_lds_bytes(s.nb);
-  if (J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT")) {
+  const bool fused_rows = J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT");
+  const uint8_t* skip = fused_rows ? J.skip : nullptr;    // the generic sort reads every digit, so nothing may be left unwritten there
+  if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig, (const uint8_t*)nullptr);
+  else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig, skip);
+  if (c->z_consumed && J.mode == MODE_ROWS) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));   // the scalars are not read again
+  if (fused_rows) {
     ProfScope _ps(c, "k_sort_rows");
-    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const dig_t*)dig, g, hist, offs, sorted);
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)J.P), dim3(1024), rows_lds, c->stream, (const dig_t*)dig, g, hist, offs, sorted, skip);
   } else {
     {
       ProfScope _ps(c, "k_hist_lds");
@@ -125,7 +128,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
   LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
-  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
   int G = chunks, logM = 6 + logL;
   for (;;) {
@@ -185,7 +188,7 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
 
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
 // launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
-static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf) {
+static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const uint8_t* skip_rows = nullptr) {
   if (L == 0) return SBN_OK;
   if (b->uniq) {
     // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
@@ -197,7 +200,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
     if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
-    return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf);
+    return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf, dBl ? nullptr : rowflags);   // with blinds a zero row still commits to blind*h
   }
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) { HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK; }
@@ -209,6 +212,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   if ((rc = bases_window_table(c, b, J.s, &tab))) return rc;
   J.points = tab;
   J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
+  J.skip = skip_rows;
   if ((rc = run_bucket_job(c, J))) return rc;
   LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
   LAUNCHCHK(c);

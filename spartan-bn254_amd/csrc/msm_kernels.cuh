@@ -79,7 +79,7 @@ typedef int16_t dig_t;
 constexpr int MSM_C_MAX = 16;
 //   SINGLE: p = window w, e = scalar index          ROWS: p = row, e = w*ncol + col
 template <int MODE>
-__global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, dig_t* __restrict__ dig) {
+__global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, dig_t* __restrict__ dig, const uint8_t* __restrict__ skip) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* k; size_t row = 0, col = 0;
   if (MODE == MODE_SINGLE) {
@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, d
   } else {
     if (t >= a.L * a.n) return;
     row = t / a.n; col = t - row * a.n;
+    if (skip && skip[row] == 2) return;                  // all-zero row: k_sort_rows never reads its digits
     k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
   }
   uint32_t carry = 0;
@@ -180,7 +181,11 @@ __global__ void __launch_bounds__(1024) k_scatter_lds(const dig_t* __restrict__ 
 // entries (by the start offset of their bucket), each range is assembled in LDS and flushed with coalesced stores.
 constexpr uint32_t SORT_SL_LOG = 15, SORT_SL = 1u << SORT_SL_LOG, SORT_SLACK = 1024, SORT_MAXR = 64;
 __host__ __device__ inline size_t sort_rows_lds_bytes(int nb) { return ((size_t)nb + (size_t)nb / 4 + 1024 + SORT_MAXR + 2 + SORT_SL + SORT_SLACK) * 4; }
-__global__ void __launch_bounds__(1024) k_sort_rows(const dig_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+__global__ void __launch_bounds__(1024) k_sort_rows(const dig_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted, const uint8_t* __restrict__ skip) {
+  if (skip && skip[blockIdx.x] == 2) {                   // all-zero row: every bucket empty
+    for (int j = threadIdx.x; j < g.nb; j += blockDim.x) { hist[(size_t)blockIdx.x * g.nb + j] = 0; offs[(size_t)blockIdx.x * g.nb + j] = 0; }
+    return;
+  }
   uint32_t* cnt = sort_lds;                                     // nb counters, then cursors
   uint8_t* rng = reinterpret_cast<uint8_t*>(sort_lds + g.nb);   // range id of every bucket (start offset >> SORT_SL_LOG; the host keeps E <= 8*SORT_SL)
   uint32_t* part = sort_lds + g.nb + g.nb / 4;                  // 1024 scan partials
@@ -419,9 +424,13 @@ __global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict_
 // level 1: one wave per chunk of 64*L consecutive buckets of one problem (window).
 //   S  = sum_i X_i ,  Wt = sum_i i * X_i   (i = 0-based index inside the chunk)
 // out[chunk] = {S, Wt}
-__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem) {
   const int lane = threadIdx.x;
   const size_t chunk = blockIdx.x;
+  if (skip && skip[chunk / chunks_per_problem] == 2) {   // all-zero row: nothing was accumulated
+    if (lane == 0) { xyzz_store(out + 64 * chunk, xyzz_inf()); xyzz_store(out + 64 * chunk + 32, xyzz_inf()); }
+    return;
+  }
   const uint32_t* base = X + 32 * ((chunk * 64 + lane) * (size_t)L);
   // lane-sequential running sums over its L buckets: run = sum X_i, acc = sum i*X_i (local i)
   XYZZ run = xyzz_inf(), acc = xyzz_inf();
@@ -524,7 +533,8 @@ __device__ __forceinline__ Fr merged_load(const uint32_t* __restrict__ Z, const 
 // Rows whose R scalars are all equal (the padded tail of every derefs matrix repeats mem[0]: sparse_mlpoly_full.rs:89-101,
 // ~43 % of the non-zero rows at keyless size) commit to v * (sum_j G_j): the unique-base table carries that sum as one
 // extra column, the row's value goes there and every other merged scalar of the row is zero (only h keeps the blind).
-// flags[row] = 1 when the row is constant.  One block per row.
+// flags[row] = 0: general row, 1: constant non-zero row, 2: all-zero row (hyrax.rs:245 padding; skipped by the later
+// stages when there are no blinds).  One block per row.
 __global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restrict__ Z, size_t R, uint8_t* __restrict__ flags) {
   const size_t row = blockIdx.x;
   const uint4* z = reinterpret_cast<const uint4*>(Z + 8 * row * R);
@@ -535,7 +545,7 @@ __global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restr
     diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
   }
   const int any = __syncthreads_or(diff != 0);
-  if (threadIdx.x == 0) flags[row] = any ? 0 : 1;
+  if (threadIdx.x == 0) flags[row] = any ? 0 : (((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w) == 0) ? 2 : 1);
 }
 // small groups: one lane per (row, merged column).  Column U is the sum-of-all-bases column; hcol = the unique base h maps to
 // (or U+1 when the table has no h).
