@@ -493,3 +493,48 @@ void orc_unipoly_eval(const uint8_t* coeffs, size_t n, const uint8_t r[32], uint
   for (size_t i = 1; i < n; i++) { fe_from_bytes(&FR, &c, coeffs + 32 * i); fe_mul(&FR, &t, &pw, &c); fe_add(&FR, &ev, &ev, &t); fe_mul(&FR, &pw, &pw, &rr); }
   fe_to_bytes(&FR, out, &ev);
 }
+
+/* ------------------------------------------------------------------ BulletReductionProof::prove (nizk/bullet.rs:41-126)
+ * The reference draws u_i from the transcript after absorbing L_i, R_i (bullet.rs:80-83); the transcript is outside the
+ * path, so the challenges are an input here.  Everything else follows the reference line by line, with plain
+ * double-and-add scalar multiplications (the mathematical definition). */
+static void jac_mul_scalar_bytes(jac* o, const aff* p, const uint8_t k[32]) { jac j; fe s; jac_from_aff(&j, p); load_le(&s, k); jac_mul_int(o, &j, s.v); }
+static void msm_def(jac* acc, const fe* k_mont, const aff* P, size_t n) {   /* sum k_i P_i, k in Montgomery form */
+  jac_set_inf(acc);
+  for (size_t i = 0; i < n; i++) { fe kc; fe_from_mont(&FR, &kc, &k_mont[i]); jac p, t; jac_from_aff(&p, &P[i]); jac_mul_int(&t, &p, kc.v); jac_add(acc, acc, &t); }
+}
+static void fr_dot_mont(fe* o, const fe* a, const fe* b, size_t n) { fe acc = {{0, 0, 0, 0}}, t; for (size_t i = 0; i < n; i++) { fe_mul(&FR, &t, &a[i], &b[i]); fe_add(&FR, &acc, &acc, &t); } *o = acc; }
+void orc_bullet_prove(const uint8_t* G_xy, const uint8_t Q_xy[64], const uint8_t H_xy[64], const uint8_t* a_in, const uint8_t* b_in, size_t n,
+                      const uint8_t blind[32], const uint8_t* blinds_vec /* lg n x (L, R) x 32 */, const uint8_t* us /* lg n x 32 */,
+                      uint8_t* L_vec, uint8_t* R_vec, uint8_t Gamma[64], uint8_t a_hat[32], uint8_t b_hat[32], uint8_t g_hat[64], uint8_t blind_hat[32]) {
+  aff* G = (aff*)malloc(sizeof(aff) * n); fe* a = (fe*)malloc(sizeof(fe) * n); fe* b = (fe*)malloc(sizeof(fe) * n);
+  for (size_t i = 0; i < n; i++) { aff_from_bytes(&G[i], G_xy + 64 * i); fe_from_bytes(&FR, &a[i], a_in + 32 * i); fe_from_bytes(&FR, &b[i], b_in + 32 * i); }
+  aff Qp, Hp; aff_from_bytes(&Qp, Q_xy); aff_from_bytes(&Hp, H_xy);
+  fe bG; fe_from_bytes(&FR, &bG, blind);
+  /* Gamma = MSM(a, G) + <a,b> Q + blind H  (bullet.rs:58-60) */
+  { jac g, t; fe d; uint8_t db[32]; msm_def(&g, a, G, n); fr_dot_mont(&d, a, b, n); fe_to_bytes(&FR, db, &d);
+    jac_mul_scalar_bytes(&t, &Qp, db); jac_add(&g, &g, &t); jac_mul_scalar_bytes(&t, &Hp, blind); jac_add(&g, &g, &t); jac_to_bytes(Gamma, &g); }
+  size_t round = 0;
+  while (n > 1) {
+    n /= 2;
+    fe cL, cR; fr_dot_mont(&cL, a, b + n, n); fr_dot_mont(&cR, a + n, b, n);          /* bullet.rs:72-73 */
+    const uint8_t* bl = blinds_vec + 64 * round; const uint8_t* br = bl + 32;
+    jac L, R, t; uint8_t sb[32];
+    msm_def(&L, a, G + n, n); fe_to_bytes(&FR, sb, &cL); jac_mul_scalar_bytes(&t, &Qp, sb); jac_add(&L, &L, &t); jac_mul_scalar_bytes(&t, &Hp, bl); jac_add(&L, &L, &t);
+    msm_def(&R, a + n, G, n); fe_to_bytes(&FR, sb, &cR); jac_mul_scalar_bytes(&t, &Qp, sb); jac_add(&R, &R, &t); jac_mul_scalar_bytes(&t, &Hp, br); jac_add(&R, &R, &t);
+    jac_to_bytes(L_vec + 64 * round, &L); jac_to_bytes(R_vec + 64 * round, &R);
+    fe u, ui; fe_from_bytes(&FR, &u, us + 32 * round); fe_inv(&FR, &ui, &u);
+    uint8_t ub[32], uib[32]; fe_to_bytes(&FR, ub, &u); fe_to_bytes(&FR, uib, &ui);
+    for (size_t i = 0; i < n; i++) {                                                   /* bullet.rs:87-106 */
+      jac x, y; jac_mul_scalar_bytes(&x, &G[i], uib); jac_mul_scalar_bytes(&y, &G[i + n], ub); jac_add(&x, &x, &y); jac_to_aff(&G[i], &x);
+      fe p, q; fe_mul(&FR, &p, &u, &a[i]); fe_mul(&FR, &q, &ui, &a[i + n]); fe_add(&FR, &a[i], &p, &q);
+      fe_mul(&FR, &p, &ui, &b[i]); fe_mul(&FR, &q, &u, &b[i + n]); fe_add(&FR, &b[i], &p, &q);
+    }
+    fe blm, brm, uu, t1; fe_from_bytes(&FR, &blm, bl); fe_from_bytes(&FR, &brm, br);   /* bullet.rs:108 */
+    fe_mul(&FR, &uu, &u, &u); fe_mul(&FR, &t1, &uu, &blm); fe_add(&FR, &bG, &bG, &t1);
+    fe_mul(&FR, &uu, &ui, &ui); fe_mul(&FR, &t1, &uu, &brm); fe_add(&FR, &bG, &bG, &t1);
+    round++;
+  }
+  fe_to_bytes(&FR, a_hat, &a[0]); fe_to_bytes(&FR, b_hat, &b[0]); aff_to_bytes(g_hat, &G[0]); fe_to_bytes(&FR, blind_hat, &bG);
+  free(G); free(a); free(b);
+}

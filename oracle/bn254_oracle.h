@@ -87,6 +87,13 @@ void orc_hash_layer(const uint32_t* addr, const uint8_t* val, const uint32_t* ts
 /* ProductCircuit::compute_layer (product_tree.rs:21-37): out[i] = in[i] * in[i + len/2], i < len/2 */
 void orc_product_layer(const uint8_t* in, size_t len, uint8_t* out);
 
+/* BulletReductionProof::prove (nizk/bullet.rs:41-126) with the Fiat-Shamir challenges u_i supplied by the caller (the
+ * reference draws them from the transcript, bullet.rs:80-83).  n a power of two; blinds_vec = lg n pairs (blind_L, blind_R);
+ * outputs: L_vec, R_vec (lg n points each), Gamma, a_hat, b_hat, g_hat, rhat_Gamma. */
+void orc_bullet_prove(const uint8_t* G_xy, const uint8_t Q_xy[64], const uint8_t H_xy[64], const uint8_t* a, const uint8_t* b, size_t n,
+                      const uint8_t blind[32], const uint8_t* blinds_vec, const uint8_t* us,
+                      uint8_t* L_vec, uint8_t* R_vec, uint8_t Gamma[64], uint8_t a_hat[32], uint8_t b_hat[32], uint8_t g_hat[64], uint8_t blind_hat[32]);
+
 /* ---- Keccak (sha3 crate call sites: commitments.rs:33-44, group.rs:113-128) ---- */
 void orc_sha3_256(const uint8_t* in, size_t len, uint8_t out[32]);
 void orc_shake256(const uint8_t* in, size_t len, uint8_t* out, size_t outlen);

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
 
@@ -339,6 +339,21 @@ class Context:
         out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
         self._chk(lib().sbn_commit_table(self.h, bases.h, t.h, _ptr(blinds), C.c_size_t(L), C.c_size_t(R), out, inf), "sbn_commit_table")
         return bytes(out), bytes(inf)
+
+    # ---- BulletReductionProof::prove rounds (nizk/bullet.rs:63-108)
+    def bullet_cross(self, G, a, b, Q_xy=None, H_xy=None, blind_L=None, blind_R=None):
+        """-> (L_xy, L_inf, R_xy, R_inf, c_L, c_R)"""
+        Lo, Ro = (C.c_uint8 * 64)(), (C.c_uint8 * 64)(); li, ri = C.c_int(0), C.c_int(0)
+        cl, cr = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        self._chk(lib().sbn_bullet_cross(self.h, G.h, a.h, b.h, _ptr(Q_xy), _ptr(H_xy), _ptr(blind_L), _ptr(blind_R),
+                                         Lo, C.byref(li), Ro, C.byref(ri), cl, cr), "sbn_bullet_cross")
+        return bytes(Lo), bool(li.value), bytes(Ro), bool(ri.value), bytes(cl), bytes(cr)
+
+    def bullet_fold(self, G, a, b, u, u_inv):
+        """folds a, b in place (their length halves) and returns the folded generators as a new Bases"""
+        o = C.c_void_p()
+        self._chk(lib().sbn_bullet_fold(self.h, G.h, a.h, b.h, _ptr(u), _ptr(u_inv), C.byref(o)), "sbn_bullet_fold")
+        return Bases(self, o)
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -30,6 +30,7 @@ using namespace sbn;
 
 #include "abi_msm.inc"
 #include "abi_tables.inc"
+#include "abi_bullet.inc"
 
 extern "C" {
 

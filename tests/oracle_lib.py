@@ -154,6 +154,16 @@ def unipoly_eval(co, r):
     out = _buf(32); lib().orc_unipoly_eval(co, C.c_size_t(len(co) // 32), r, out); return _b(out)
 
 
+def bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us):
+    """nizk/bullet.rs:41-126 with caller-supplied challenges -> dict"""
+    n = len(a) // 32
+    lg = n.bit_length() - 1
+    Lv, Rv = _buf(64 * lg), _buf(64 * lg)
+    Gm, ah, bh, gh, blh = _buf(64), _buf(32), _buf(32), _buf(64), _buf(32)
+    lib().orc_bullet_prove(_b(G_xy), _b(Q_xy), _b(H_xy), _b(a), _b(b), C.c_size_t(n), _b(blind), _b(blinds_vec), _b(us), Lv, Rv, Gm, ah, bh, gh, blh)
+    return dict(L=bytes(Lv), R=bytes(Rv), Gamma=bytes(Gm), a_hat=bytes(ah), b_hat=bytes(bh), g_hat=bytes(gh), blind_hat=bytes(blh))
+
+
 def sha3_256(m):
     out = _buf(32); lib().orc_sha3_256(m, C.c_size_t(len(m)), out); return _b(out)
 

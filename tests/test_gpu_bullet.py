@@ -1,0 +1,138 @@
+"""BulletReductionProof::prove (nizk/bullet.rs:41-126) round by round through the C ABI vs the oracle's restatement.
+The Fiat-Shamir challenges are test inputs (the transcript stays in Rust)."""
+import pytest
+
+from conftest import rand_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def _inv(pr, ub):
+    return pr.scalar_to_bytes(pow(pr.scalar_from_bytes(ub), pr.R - 2, pr.R))
+
+
+def _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us):
+    n = len(a) // 32
+    G = ctx.bases_upload(G_xy, H_xy)
+    ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+    Ls, Rs = [], []
+    blind_hat = pr.scalar_from_bytes(blind)
+    rnd = 0
+    while n > 1:
+        bl, br = blinds_vec[64 * rnd:64 * rnd + 32], blinds_vec[64 * rnd + 32:64 * rnd + 64]
+        L, _, Rp, _, cL, cR = ctx.bullet_cross(G, ta, tb, Q_xy, H_xy, bl, br)
+        Ls.append(L); Rs.append(Rp)
+        u = us[32 * rnd:32 * rnd + 32]; ui = _inv(pr, u)
+        G2 = ctx.bullet_fold(G, ta, tb, u, ui)
+        G.free(); G = G2
+        uv, uiv = pr.scalar_from_bytes(u), pr.scalar_from_bytes(ui)
+        blind_hat = (uv * uv * pr.scalar_from_bytes(bl) + blind_hat + uiv * uiv * pr.scalar_from_bytes(br)) % pr.R   # bullet.rs:108 (host side)
+        n //= 2; rnd += 1
+        assert len(ta) == n and len(tb) == n and len(G) == n
+    out = dict(L=b"".join(Ls), R=b"".join(Rs), a_hat=ctx.table_read0(ta), b_hat=ctx.table_read0(tb),
+               g_hat=ctx.bases_download(G, 0, 1), blind_hat=pr.scalar_to_bytes(blind_hat))
+    G.free(); ta.free(); tb.free()
+    return out
+
+
+@pytest.mark.parametrize("n,label", [(2, b"test-gens"), (8, b"test-gens"), (64, b"gens_r1cs_eval")])
+def test_bullet_rounds_vs_oracle(ctx, ol, pr, n, label):
+    # n = 8 with label "test-gens" and Q = G is the reference's own test setup (bullet.rs:222-238)
+    pts, _ = ol.gens_new(n, label)
+    G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+    Q_xy = pr.point_to_xy((1, 2))
+    lg = n.bit_length() - 1
+    a, b = rand_scalars(n, 101 + n), rand_scalars(n, 202 + n)
+    blind = rand_scalars(1, 303)
+    blinds_vec, us = rand_scalars(2 * lg, 404 + n), rand_scalars(lg, 505 + n)
+    want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
+    got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+    for k in ("L", "R", "a_hat", "b_hat", "g_hat", "blind_hat"):
+        assert got[k] == want[k], k
+
+
+def test_bullet_edge_values(ctx, ol, pr):
+    """zero / one / r-1 entries, equal generators (the reference's derivation repeats G), zero blinds, u = 1"""
+    n = 16
+    pts, _ = ol.gens_new(n, b"gens_r1cs_eval")      # ~2/3 of these equal the curve generator
+    G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+    Q_xy = pr.point_to_xy(pr.mul((1, 2), 7))
+    vals = [0, 1, pr.R - 1, 2, 0, 0, pr.R - 2, 5] * 2
+    a = b"".join(pr.scalar_to_bytes(v) for v in vals)
+    b = b"".join(pr.scalar_to_bytes(v) for v in reversed(vals))
+    blind = pr.scalar_to_bytes(0)
+    blinds_vec = b"".join(pr.scalar_to_bytes(v) for v in [0, 0, 1, pr.R - 1, 0, 3, 9, 0])
+    us = b"".join(pr.scalar_to_bytes(v) for v in [1, pr.R - 1, 2, 12345])
+    want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
+    got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+    for k in ("L", "R", "a_hat", "b_hat", "g_hat", "blind_hat"):
+        assert got[k] == want[k], k
+
+
+def test_bullet_optional_terms(ctx, ol, pr):
+    """Q / H left out: L and R are the bare MSMs (what vartime_multiscalar_mul(a_L, G_R) returns, bullet.rs:77)"""
+    n = 32
+    pts, _ = ol.gens_new(n, b"opt")
+    G_xy = pts[:64 * n]
+    a, b = rand_scalars(n, 1), rand_scalars(n, 2)
+    G = ctx.bases_upload(G_xy, None)
+    ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+    L, _, Rp, _, cL, cR = ctx.bullet_cross(G, ta, tb)
+    h = n // 2
+    assert L == ol.msm_naive(a[:32 * h], G_xy[64 * h:])
+    assert Rp == ol.msm_naive(a[32 * h:], G_xy[:64 * h])
+    assert cL == ol.fr_dot(a[:32 * h], b[32 * h:]) and cR == ol.fr_dot(a[32 * h:], b[:32 * h])
+    G.free(); ta.free(); tb.free()
+
+
+def test_bullet_errors(ctx, sbn, ol, pr):
+    pts, _ = ol.gens_new(8, b"e")
+    G = ctx.bases_upload(pts[:64 * 8], pts[64 * 8:])
+    ta, tb = ctx.table_upload(rand_scalars(8, 1)), ctx.table_upload(rand_scalars(4, 2))
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_cross(G, ta, tb)                       # bullet.rs:43 assert_eq
+    t1, t1b = ctx.table_upload(rand_scalars(1, 3)), ctx.table_upload(rand_scalars(1, 4))
+    G1 = ctx.bases_upload(pts[:64], None)
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_cross(G1, t1, t1b)                     # nothing left to fold
+    bad = b"\xff" * 32
+    tc = ctx.table_upload(rand_scalars(8, 5))
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_fold(G, ta, tc, bad, bad)
+    for t in (ta, tb, t1, t1b, tc):
+        t.free()
+    G.free(); G1.free()
+
+
+def test_bullet_full_size_verifier_relation(ctx, ol, pr):
+    """n = 8192 (the right-hand vector of the derefs opening): check what the verifier checks (bullet.rs:155-170 and
+    nizk/mod.rs DotProductProofLog::verify): g_hat = MSM(s, G), b_hat = <s, b>,
+    sum u_i^2 L_i + Gamma + sum u_i^-2 R_i = a_hat*g_hat + a_hat*b_hat*Q + rhat*H."""
+    n = 8192; lg = 13
+    pts, _ = ol.gens_new(n, b"gens_r1cs_eval")
+    G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+    Q_xy = pr.point_to_xy(pr.mul((1, 2), 0xABCDEF))
+    a, b = rand_scalars(n, 11), rand_scalars(n, 12)
+    blind = rand_scalars(1, 13); blinds_vec = rand_scalars(2 * lg, 14); us = rand_scalars(lg, 15)
+    got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+    R = pr.R
+    u = [pr.scalar_from_bytes(us[32 * i:32 * i + 32]) for i in range(lg)]
+    ui = [pow(x, R - 2, R) for x in u]
+    s = []
+    for i in range(n):                                   # compute_s (bullet.rs:181-199)
+        v = 1
+        for j in range(lg):
+            v = v * (u[lg - 1 - j] if (i >> j) & 1 else ui[lg - 1 - j]) % R
+        s.append(v)
+    sb = b"".join(pr.scalar_to_bytes(v) for v in s)
+    assert got["g_hat"] == ol.msm_pippenger(sb, G_xy, threads=8)
+    assert got["b_hat"] == ol.fr_dot(sb, b)
+    ab = ol.fr_dot(a, b)
+    Gamma = ol.g1_add(ol.g1_add(ol.msm_pippenger(a, G_xy, threads=8), ol.g1_mul(Q_xy, ab)), ol.g1_mul(H_xy, blind))
+    lhs = Gamma
+    for i in range(lg):
+        lhs = ol.g1_add(lhs, ol.g1_mul(got["L"][64 * i:64 * i + 64], pr.scalar_to_bytes(u[i] * u[i] % R)))
+        lhs = ol.g1_add(lhs, ol.g1_mul(got["R"][64 * i:64 * i + 64], pr.scalar_to_bytes(ui[i] * ui[i] % R)))
+    ah, bh = pr.scalar_from_bytes(got["a_hat"]), pr.scalar_from_bytes(got["b_hat"])
+    rhs = ol.g1_add(ol.g1_add(ol.g1_mul(got["g_hat"], got["a_hat"]), ol.g1_mul(Q_xy, pr.scalar_to_bytes(ah * bh % R))), ol.g1_mul(H_xy, got["blind_hat"]))
+    assert lhs == rhs

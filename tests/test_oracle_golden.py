@@ -167,3 +167,42 @@ def test_pippenger_vs_naive_vs_python(ol, pr, n):
         ks = [int.from_bytes(sc[32 * i:32 * i + 32], "little") for i in range(n)]
         ps = [pr.point_from_xy(pts[64 * i:64 * i + 64]) for i in range(n)]
         assert pr.point_to_xy(pr.msm(ks, ps)) == want
+
+
+def test_oracle_bullet_reduction_verifier_relations(ol, pr):
+    """The reference's own test for this function (nizk/bullet.rs:215-255: n = 8, gens label "test-gens", Q = generator) is a
+    prove -> verify round trip; the relations its verifier (bullet.rs:155-170) and DotProductProofLog::verify rely on must hold
+    for the oracle's restatement: g_hat = MSM(s, G), b_hat = <s, b>, sum u^2 L + Gamma + sum u^-2 R = a_hat g_hat + a_hat b_hat Q + rhat H.
+    The group side is re-derived with the independent pure-Python model."""
+    from conftest import rand_scalars
+    n, lg = 8, 3
+    pts, dl = ol.gens_new(n, b"test-gens")
+    G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+    Q = (1, 2); Q_xy = pr.point_to_xy(Q)
+    a, b = rand_scalars(n, 1), rand_scalars(n, 2)
+    blind = rand_scalars(1, 3); blinds_vec = rand_scalars(2 * lg, 4); us = rand_scalars(lg, 5)
+    o = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
+    R = pr.R
+    sc = lambda bs, i: pr.scalar_from_bytes(bs[32 * i:32 * i + 32])
+    u = [sc(us, i) for i in range(lg)]; ui = [pow(x, R - 2, R) for x in u]
+    s = []
+    for i in range(n):
+        v = 1
+        for j in range(lg):
+            v = v * (u[lg - 1 - j] if (i >> j) & 1 else ui[lg - 1 - j]) % R
+        s.append(v)
+    G = [pr.point_from_xy(G_xy[64 * i:64 * i + 64]) for i in range(n)]
+    H = pr.point_from_xy(H_xy)
+    av = [sc(a, i) for i in range(n)]; bv = [sc(b, i) for i in range(n)]
+    assert pr.point_to_xy(pr.msm(s, G)) == o["g_hat"]
+    assert sum(x * y for x, y in zip(s, bv)) % R == pr.scalar_from_bytes(o["b_hat"])
+    assert sum(pow(x, R - 2, R) * y for x, y in zip(s, av)) % R == pr.scalar_from_bytes(o["a_hat"])   # a folds with u on the left half (bullet.rs:94-98)
+    Gamma = pr.add(pr.add(pr.msm(av, G), pr.mul(Q, sum(x * y for x, y in zip(av, bv)) % R)), pr.mul(H, sc(blind, 0)))
+    assert pr.point_to_xy(Gamma) == o["Gamma"]
+    lhs = Gamma
+    for i in range(lg):
+        lhs = pr.add(lhs, pr.mul(pr.point_from_xy(o["L"][64 * i:64 * i + 64]), u[i] * u[i] % R))
+        lhs = pr.add(lhs, pr.mul(pr.point_from_xy(o["R"][64 * i:64 * i + 64]), ui[i] * ui[i] % R))
+    ah, bh, rh = (pr.scalar_from_bytes(o[k]) for k in ("a_hat", "b_hat", "blind_hat"))
+    rhs = pr.add(pr.add(pr.mul(pr.point_from_xy(o["g_hat"]), ah), pr.mul(Q, ah * bh % R)), pr.mul(H, rh))
+    assert lhs == rhs

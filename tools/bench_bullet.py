@@ -1,0 +1,34 @@
+"""Time BulletReductionProof::prove's device work (nizk/bullet.rs:63-108) at n = 8192 (the derefs opening's right-hand vector):
+13 rounds of sbn_bullet_cross + sbn_bullet_fold, challenges fixed.  Usage: python tools/bench_bullet.py [log_n]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_pkg, rand_scalars  # noqa: E402
+
+sbn = load_pkg()
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+n = 1 << lg
+ctx = sbn.Context(0)
+gens, pts = ctx.gens_new(n, b"gens_r1cs_eval")
+G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+Q_xy = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+a, b = rand_scalars(n, 1), rand_scalars(n, 2)
+bl = rand_scalars(2 * lg, 3); us = rand_scalars(lg, 4)
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+uis = b"".join(pow(int.from_bytes(us[32 * i:32 * i + 32], "little"), R - 2, R).to_bytes(32, "little") for i in range(lg))
+for rep in range(3):
+    G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+    ctx.sync(); t0 = time.perf_counter(); tc = tf = 0.0
+    for r in range(lg):
+        t1 = time.perf_counter()
+        ctx.bullet_cross(G, ta, tb, Q_xy, H_xy, bl[64 * r:64 * r + 32], bl[64 * r + 32:64 * r + 64])
+        t2 = time.perf_counter()
+        G2 = ctx.bullet_fold(G, ta, tb, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
+        t3 = time.perf_counter()
+        G.free(); G = G2; tc += t2 - t1; tf += t3 - t2
+    dt = time.perf_counter() - t0
+    print(f"n=2^{lg}: {lg} rounds {dt * 1e3:.2f} ms  (cross terms {tc * 1e3:.2f} ms, folds {tf * 1e3:.2f} ms)")
+    G.free(); ta.free(); tb.free()
