@@ -155,19 +155,29 @@ int sbn_table_evaluate(sbn_ctx* ctx, const sbn_table* Z, const uint8_t* r, size_
  * out[i] = sum_j Lvec[j] * Z[j*R_size + i]  (a new table of R_size entries) */
 int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn_table** out);
 
-/* ---- BulletReductionProof::prove (nizk/bullet.rs:41-126) round by round on resident data; the transcript stays with the
- *      caller.  G: the current generators (n = len(a) = len(b), a power of two >= 2); a, b: the current vectors. ----
- * One round's cross terms (bullet.rs:72-78), h = n/2:
+/* ---- BulletReductionProof::prove (nizk/bullet.rs:41-126) as a device-resident state; the transcript stays with the caller:
+ *      begin, then per round cross -> (absorb L, R; squeeze u) -> fold, then finish.
+ * The generators are never folded (bullet.rs:87-91 costs n 254-bit scalar multiplications per round): round j's L and R are
+ * MSMs over the ORIGINAL generators with scalars a[..] * s_t, s_t the running product of the u / u_inv the fold would have
+ * applied to G_t (the verifier's compute_s, bullet.rs:181-199); g_hat = MSM(s, G).  Same group elements, bit for bit. ----
+ * begin: G = the n generators (+ h = H if the handle has one; it must outlive the state), Q_xy = canonical affine Q or NULL
+ *   (term left out), a / b = the two vectors (copied, as bullet.rs:50-52 clones them).  If Gamma_xy != NULL it receives
+ *   Gamma = MSM(a, G) + <a, b>*Q + blind*H (bullet.rs:58-60; blind NULL = 0). */
+typedef struct sbn_bullet sbn_bullet;
+int sbn_bullet_begin(sbn_ctx* ctx, const sbn_bases* G, const uint8_t* Q_xy, const sbn_table* a, const sbn_table* b, const uint8_t* blind,
+                     uint8_t* Gamma_xy, int* Gamma_is_inf, sbn_bullet** out);
+void sbn_bullet_free(sbn_ctx* ctx, sbn_bullet* st);
+size_t sbn_bullet_len(const sbn_bullet* st);       /* current n (halves per fold) */
+/* One round's cross terms (bullet.rs:72-78), h = n/2:
  *   c_L = <a[..h], b[h..]>,  c_R = <a[h..], b[..h]>,
- *   L = MSM(a[..h], G[h..]) + c_L*Q + blind_L*H,   R = MSM(a[h..], G[..h]) + c_R*Q + blind_R*H.
- * Q_xy / H_xy: canonical affine points or NULL to leave the term out; blind_L / blind_R: canonical scalars or NULL (= 0). */
-int sbn_bullet_cross(sbn_ctx* ctx, const sbn_bases* G, const sbn_table* a, const sbn_table* b, const uint8_t* Q_xy, const uint8_t* H_xy,
-                     const uint8_t* blind_L, const uint8_t* blind_R, uint8_t L_xy[64], int* L_is_inf, uint8_t R_xy[64], int* R_is_inf,
-                     uint8_t c_L[32], uint8_t c_R[32]);
-/* The folds after the challenge u (bullet.rs:86-106): *G_out = [u_inv*G[i] + u*G[i+h]] (a new handle of h points, h of G carried
- * over; free G yourself), a <- u*a_L + u_inv*a_R and b <- u_inv*b_L + u*b_R in place (their length halves). */
-int sbn_bullet_fold(sbn_ctx* ctx, const sbn_bases* G, sbn_table* a, sbn_table* b, const uint8_t u[32], const uint8_t u_inv[32],
-                    sbn_bases** G_out);
+ *   L = MSM(a[..h], G[h..]) + c_L*Q + blind_L*H,   R = MSM(a[h..], G[..h]) + c_R*Q + blind_R*H   (blinds: canonical or NULL = 0) */
+int sbn_bullet_cross(sbn_ctx* ctx, sbn_bullet* st, const uint8_t* blind_L, const uint8_t* blind_R, uint8_t L_xy[64], int* L_is_inf,
+                     uint8_t R_xy[64], int* R_is_inf, uint8_t c_L[32], uint8_t c_R[32]);
+/* The folds after the challenge u (bullet.rs:86-106): G <- u_inv*G_L + u*G_R (kept as coefficients), a <- u*a_L + u_inv*a_R,
+ * b <- u_inv*b_L + u*b_R; the length halves. */
+int sbn_bullet_fold(sbn_ctx* ctx, sbn_bullet* st, const uint8_t u[32], const uint8_t u_inv[32]);
+/* After the last fold (length 1): a_hat, b_hat, g_hat (bullet.rs:114-120) */
+int sbn_bullet_finish(sbn_ctx* ctx, sbn_bullet* st, uint8_t a_hat[32], uint8_t b_hat[32], uint8_t g_hat_xy[64], int* g_hat_is_inf);
 
 /* ---- network construction pieces ----
  * Layers::build_hash_layer (sparse_mlpoly_full.rs:745-796): out[j] = (ts[j] + ts_add) * r_hash^2 + val[j] * r_hash + addr[j] - r_multiset

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
 ]
 
 
@@ -57,8 +57,9 @@ def lib():
             raise SbnError(f"{p} does not export {missing}; rebuild it")
         L.sbn_bases_len.restype = C.c_size_t
         L.sbn_table_len.restype = C.c_size_t
+        L.sbn_bullet_len.restype = C.c_size_t
         L.sbn_factored_lens.restype = None
-        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free"):
+        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free", "sbn_bullet_free"):
             getattr(L, name).restype = None
         _LIB = L
     return _LIB
@@ -127,6 +128,19 @@ class Bases:
     def free(self):
         if self.h:
             lib().sbn_bases_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Bullet:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, handle
+
+    def __len__(self):
+        return lib().sbn_bullet_len(self.h)
+
+    def free(self):
+        if self.h:
+            lib().sbn_bullet_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -340,20 +354,28 @@ class Context:
         self._chk(lib().sbn_commit_table(self.h, bases.h, t.h, _ptr(blinds), C.c_size_t(L), C.c_size_t(R), out, inf), "sbn_commit_table")
         return bytes(out), bytes(inf)
 
-    # ---- BulletReductionProof::prove rounds (nizk/bullet.rs:63-108)
-    def bullet_cross(self, G, a, b, Q_xy=None, H_xy=None, blind_L=None, blind_R=None):
+    # ---- BulletReductionProof::prove (nizk/bullet.rs:41-126) as a device-resident state
+    def bullet_begin(self, G, Q_xy, a, b, blind=None, want_gamma=True):
+        """-> (Bullet state, Gamma_xy or None)"""
+        st = C.c_void_p(); gm = (C.c_uint8 * 64)() if want_gamma else None; gi = C.c_int(0)
+        self._chk(lib().sbn_bullet_begin(self.h, G.h, _ptr(Q_xy), a.h, b.h, _ptr(blind), gm, C.byref(gi), C.byref(st)), "sbn_bullet_begin")
+        return Bullet(self, st), (bytes(gm) if want_gamma else None)
+
+    def bullet_cross(self, st, blind_L=None, blind_R=None):
         """-> (L_xy, L_inf, R_xy, R_inf, c_L, c_R)"""
         Lo, Ro = (C.c_uint8 * 64)(), (C.c_uint8 * 64)(); li, ri = C.c_int(0), C.c_int(0)
         cl, cr = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
-        self._chk(lib().sbn_bullet_cross(self.h, G.h, a.h, b.h, _ptr(Q_xy), _ptr(H_xy), _ptr(blind_L), _ptr(blind_R),
-                                         Lo, C.byref(li), Ro, C.byref(ri), cl, cr), "sbn_bullet_cross")
+        self._chk(lib().sbn_bullet_cross(self.h, st.h, _ptr(blind_L), _ptr(blind_R), Lo, C.byref(li), Ro, C.byref(ri), cl, cr), "sbn_bullet_cross")
         return bytes(Lo), bool(li.value), bytes(Ro), bool(ri.value), bytes(cl), bytes(cr)
 
-    def bullet_fold(self, G, a, b, u, u_inv):
-        """folds a, b in place (their length halves) and returns the folded generators as a new Bases"""
-        o = C.c_void_p()
-        self._chk(lib().sbn_bullet_fold(self.h, G.h, a.h, b.h, _ptr(u), _ptr(u_inv), C.byref(o)), "sbn_bullet_fold")
-        return Bases(self, o)
+    def bullet_fold(self, st, u, u_inv):
+        self._chk(lib().sbn_bullet_fold(self.h, st.h, _ptr(u), _ptr(u_inv)), "sbn_bullet_fold")
+
+    def bullet_finish(self, st):
+        """-> (a_hat, b_hat, g_hat_xy)"""
+        ah, bh, gh = (C.c_uint8 * 32)(), (C.c_uint8 * 32)(), (C.c_uint8 * 64)(); gi = C.c_int(0)
+        self._chk(lib().sbn_bullet_finish(self.h, st.h, ah, bh, gh, C.byref(gi)), "sbn_bullet_finish")
+        return bytes(ah), bytes(bh), bytes(gh)
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -39,6 +39,8 @@ struct sbn_bases {
   sbn_bases* uniq = nullptr;
   size_t U = 0; uint32_t nbig = 0; uint32_t hcol = 0;   // hcol: the unique base h maps to
   void* d_csr_off = nullptr; void* d_csr_cols = nullptr; void* d_big = nullptr;
+  // bullet reduction (abi_bullet.inc): derived sets G ‖ Q (+ h), one per distinct Q, built on first use and owned by this handle
+  mutable std::vector<std::pair<std::string, sbn_bases*>> bullet_ext;
 };
 static const uint32_t MERGE_BIG = 64;
 extern "C" void sbn_bases_free(sbn_ctx* c, sbn_bases* b);

@@ -17,9 +17,19 @@ static MsmShape make_shape(int c) {
 // Window size from a cost model in modular products: `terms`*W mixed adds (10 each) into `sets` bucket sets of 2^(c-1)
 // buckets, each bucket costing ~2 full adds (14 each) in the running-sum reduction (x2 for the wave-level part).
 // SBN_MSM_C overrides for experiments.
-static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax) {
+// Small jobs (`problems` x `terms` far below the chip's lane count) are latency-bound: what counts is the length of the longest
+// bucket chain, not the number of products, so they take the smallest window with a mean bucket load <= 4.
+static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, size_t problems = 0) {
   const char* env = getenv("SBN_MSM_C");
   if (env && atoi(env) >= 7 && atoi(env) <= MSM_C_MAX) return make_shape(atoi(env));
+  if (cmax > MSM_C_MAX) cmax = MSM_C_MAX;
+  if (problems && problems * terms <= 32768) {
+    for (int c = 7; c <= cmax; c++) {
+      MsmShape s = make_shape(c);
+      const double load = shared_bucket_set ? (double)terms * s.W / s.nb : (double)terms / s.nb;
+      if (load <= 4.0 || c == cmax) return s;
+    }
+  }
   double best = 1e300; int bc = 7;
   // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
   // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows.
@@ -147,7 +157,7 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
   if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
   if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
   BucketJob J; memset(&J, 0, sizeof J);
-  J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
+  J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1, 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
   J.da.scalars = d_scal; J.da.n = n; J.da.estride = n;
   int rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;
@@ -188,6 +198,7 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
 
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
 // launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
+// (d_xy == nullptr: stop before the conversion and leave the L sums as XYZZ in c->wsum)
 static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const uint8_t* skip_rows = nullptr) {
   if (L == 0) return SBN_OK;
   if (b->uniq) {
@@ -203,9 +214,12 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf, dBl ? nullptr : rowflags);   // with blinds a zero row still commits to blind*h
   }
   const size_t ncol = R + (dBl ? 1 : 0);
-  if (ncol == 0) { HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK; }
+  if (ncol == 0) {
+    if (!d_xy) { int rc0; if ((rc0 = ensure(c, c->wsum, L * 128))) return rc0; HIPCHK(c, hipMemsetAsync(c->wsum.p, 0, L * 128, c->stream)); return SBN_OK; }
+    HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK;
+  }
   BucketJob J; memset(&J, 0, sizeof J);
-  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16); J.P = L; J.threads = L * ncol;
+  J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16, L); J.P = L; J.threads = L * ncol;
   const size_t npts = b->n + (b->has_h ? 1 : 0);
   if ((size_t)J.s.W * npts > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: table index overflow");
   int rc; const uint32_t* tab;
@@ -214,7 +228,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
   J.skip = skip_rows;
   if ((rc = run_bucket_job(c, J))) return rc;
-  LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
+  if (d_xy) LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
   LAUNCHCHK(c);
   return SBN_OK;
 }
@@ -222,6 +236,17 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
 static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
   if (L == 0) return SBN_OK;
   int rc;
+  if (L <= 16) {
+    // a handful of rows: the per-row Fermat inversion is a ~0.3 ms single-lane chain on the device and ~15 us on a host core
+    if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 128)))) return rc;
+    if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, nullptr, nullptr))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, L * 128, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->prof) prof_drain(c);
+    const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
+    for (size_t i = 0; i < L; i++) { int inf = 0; sbn_host::to_affine_bytes(S[i], out_xy + 64 * i, &inf); if (out_inf) out_inf[i] = (uint8_t)inf; }
+    return SBN_OK;
+  }
   if ((rc = ensure(c, c->out_small, L * 65))) return rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
   if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64))) return rc;

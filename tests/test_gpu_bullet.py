@@ -15,23 +15,24 @@ def _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us):
     n = len(a) // 32
     G = ctx.bases_upload(G_xy, H_xy)
     ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+    st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, blind)
+    ta.free(); tb.free()                                   # the state holds its own copies (bullet.rs:50-52)
     Ls, Rs = [], []
     blind_hat = pr.scalar_from_bytes(blind)
     rnd = 0
     while n > 1:
         bl, br = blinds_vec[64 * rnd:64 * rnd + 32], blinds_vec[64 * rnd + 32:64 * rnd + 64]
-        L, _, Rp, _, cL, cR = ctx.bullet_cross(G, ta, tb, Q_xy, H_xy, bl, br)
+        L, _, Rp, _, cL, cR = ctx.bullet_cross(st, bl, br)
         Ls.append(L); Rs.append(Rp)
         u = us[32 * rnd:32 * rnd + 32]; ui = _inv(pr, u)
-        G2 = ctx.bullet_fold(G, ta, tb, u, ui)
-        G.free(); G = G2
+        ctx.bullet_fold(st, u, ui)
         uv, uiv = pr.scalar_from_bytes(u), pr.scalar_from_bytes(ui)
         blind_hat = (uv * uv * pr.scalar_from_bytes(bl) + blind_hat + uiv * uiv * pr.scalar_from_bytes(br)) % pr.R   # bullet.rs:108 (host side)
         n //= 2; rnd += 1
-        assert len(ta) == n and len(tb) == n and len(G) == n
-    out = dict(L=b"".join(Ls), R=b"".join(Rs), a_hat=ctx.table_read0(ta), b_hat=ctx.table_read0(tb),
-               g_hat=ctx.bases_download(G, 0, 1), blind_hat=pr.scalar_to_bytes(blind_hat))
-    G.free(); ta.free(); tb.free()
+        assert len(st) == n
+    a_hat, b_hat, g_hat = ctx.bullet_finish(st)
+    out = dict(L=b"".join(Ls), R=b"".join(Rs), Gamma=Gamma, a_hat=a_hat, b_hat=b_hat, g_hat=g_hat, blind_hat=pr.scalar_to_bytes(blind_hat))
+    st.free(); G.free()
     return out
 
 
@@ -47,7 +48,7 @@ def test_bullet_rounds_vs_oracle(ctx, ol, pr, n, label):
     blinds_vec, us = rand_scalars(2 * lg, 404 + n), rand_scalars(lg, 505 + n)
     want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
     got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
-    for k in ("L", "R", "a_hat", "b_hat", "g_hat", "blind_hat"):
+    for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
         assert got[k] == want[k], k
 
 
@@ -65,43 +66,60 @@ def test_bullet_edge_values(ctx, ol, pr):
     us = b"".join(pr.scalar_to_bytes(v) for v in [1, pr.R - 1, 2, 12345])
     want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
     got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
-    for k in ("L", "R", "a_hat", "b_hat", "g_hat", "blind_hat"):
+    for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
         assert got[k] == want[k], k
 
 
 def test_bullet_optional_terms(ctx, ol, pr):
-    """Q / H left out: L and R are the bare MSMs (what vartime_multiscalar_mul(a_L, G_R) returns, bullet.rs:77)"""
+    """Q / H left out: L and R are the bare MSMs (what vartime_multiscalar_mul(a_L, G_R) returns, bullet.rs:77); second round too"""
     n = 32
     pts, _ = ol.gens_new(n, b"opt")
     G_xy = pts[:64 * n]
     a, b = rand_scalars(n, 1), rand_scalars(n, 2)
     G = ctx.bases_upload(G_xy, None)
     ta, tb = ctx.table_upload(a), ctx.table_upload(b)
-    L, _, Rp, _, cL, cR = ctx.bullet_cross(G, ta, tb)
+    st, Gamma = ctx.bullet_begin(G, None, ta, tb)
+    assert Gamma == ol.msm_naive(a, G_xy)
+    L, _, Rp, _, cL, cR = ctx.bullet_cross(st)
     h = n // 2
     assert L == ol.msm_naive(a[:32 * h], G_xy[64 * h:])
     assert Rp == ol.msm_naive(a[32 * h:], G_xy[:64 * h])
     assert cL == ol.fr_dot(a[:32 * h], b[32 * h:]) and cR == ol.fr_dot(a[32 * h:], b[:32 * h])
-    G.free(); ta.free(); tb.free()
+    # the caller's tables are untouched
+    assert ctx.table_download(ta) == a and ctx.table_download(tb) == b
+    st.free(); G.free(); ta.free(); tb.free()
 
 
 def test_bullet_errors(ctx, sbn, ol, pr):
     pts, _ = ol.gens_new(8, b"e")
     G = ctx.bases_upload(pts[:64 * 8], pts[64 * 8:])
+    Gnoh = ctx.bases_upload(pts[:64 * 8], None)
     ta, tb = ctx.table_upload(rand_scalars(8, 1)), ctx.table_upload(rand_scalars(4, 2))
     with pytest.raises(sbn.SbnError):
-        ctx.bullet_cross(G, ta, tb)                       # bullet.rs:43 assert_eq
-    t1, t1b = ctx.table_upload(rand_scalars(1, 3)), ctx.table_upload(rand_scalars(1, 4))
-    G1 = ctx.bases_upload(pts[:64], None)
+        ctx.bullet_begin(G, None, ta, tb)                 # bullet.rs:43 assert_eq
     with pytest.raises(sbn.SbnError):
-        ctx.bullet_cross(G1, t1, t1b)                     # nothing left to fold
-    bad = b"\xff" * 32
+        ctx.table_upload(rand_scalars(6, 3))              # tables are powers of two, so bullet.rs:44 cannot be violated
     tc = ctx.table_upload(rand_scalars(8, 5))
     with pytest.raises(sbn.SbnError):
-        ctx.bullet_fold(G, ta, tc, bad, bad)
-    for t in (ta, tb, t1, t1b, tc):
+        ctx.bullet_begin(Gnoh, None, ta, tc, rand_scalars(1, 6))     # blind without h
+    st, _ = ctx.bullet_begin(G, None, ta, tc)
+    bad = b"\xff" * 32
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_fold(st, bad, bad)
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_cross(st, bad, None)
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_finish(st)                             # bullet.rs:114-116: length must be 1
+    one = pr.scalar_to_bytes(1)
+    for _ in range(3):
+        ctx.bullet_fold(st, one, one)
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_cross(st)                              # nothing left to fold
+    ctx.bullet_finish(st)
+    st.free()
+    for t in (ta, tb, tc):
         t.free()
-    G.free(); G1.free()
+    G.free(); Gnoh.free()
 
 
 def test_bullet_full_size_verifier_relation(ctx, ol, pr):
@@ -129,6 +147,7 @@ def test_bullet_full_size_verifier_relation(ctx, ol, pr):
     assert got["b_hat"] == ol.fr_dot(sb, b)
     ab = ol.fr_dot(a, b)
     Gamma = ol.g1_add(ol.g1_add(ol.msm_pippenger(a, G_xy, threads=8), ol.g1_mul(Q_xy, ab)), ol.g1_mul(H_xy, blind))
+    assert got["Gamma"] == Gamma
     lhs = Gamma
     for i in range(lg):
         lhs = ol.g1_add(lhs, ol.g1_mul(got["L"][64 * i:64 * i + 64], pr.scalar_to_bytes(u[i] * u[i] % R)))

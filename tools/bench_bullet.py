@@ -19,16 +19,35 @@ a, b = rand_scalars(n, 1), rand_scalars(n, 2)
 bl = rand_scalars(2 * lg, 3); us = rand_scalars(lg, 4)
 R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 uis = b"".join(pow(int.from_bytes(us[32 * i:32 * i + 32], "little"), R - 2, R).to_bytes(32, "little") for i in range(lg))
+G = ctx.bases_upload(G_xy, H_xy)
 for rep in range(3):
-    G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+    ta, tb = ctx.table_upload(a), ctx.table_upload(b)
     ctx.sync(); t0 = time.perf_counter(); tc = tf = 0.0
+    st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, us[:32])
+    tb0 = time.perf_counter() - t0
     for r in range(lg):
         t1 = time.perf_counter()
-        ctx.bullet_cross(G, ta, tb, Q_xy, H_xy, bl[64 * r:64 * r + 32], bl[64 * r + 32:64 * r + 64])
+        ctx.bullet_cross(st, bl[64 * r:64 * r + 32], bl[64 * r + 32:64 * r + 64])
         t2 = time.perf_counter()
-        G2 = ctx.bullet_fold(G, ta, tb, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
+        ctx.bullet_fold(st, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
         t3 = time.perf_counter()
-        G.free(); G = G2; tc += t2 - t1; tf += t3 - t2
+        tc += t2 - t1; tf += t3 - t2
+    t4 = time.perf_counter()
+    ctx.bullet_finish(st)
+    te = time.perf_counter() - t4
     dt = time.perf_counter() - t0
-    print(f"n=2^{lg}: {lg} rounds {dt * 1e3:.2f} ms  (cross terms {tc * 1e3:.2f} ms, folds {tf * 1e3:.2f} ms)")
-    G.free(); ta.free(); tb.free()
+    print(f"n=2^{lg}: {lg} rounds {dt * 1e3:.2f} ms  (begin+Gamma {tb0 * 1e3:.2f}, cross terms {tc * 1e3:.2f}, folds {tf * 1e3:.2f}, finish {te * 1e3:.2f} ms)")
+    st.free(); ta.free(); tb.free()
+G.free()
+# per-kernel view of one cross round (HIP events)
+G = ctx.bases_upload(G_xy, H_xy)
+ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+st, _ = ctx.bullet_begin(G, Q_xy, ta, tb, us[:32])
+ctx.bullet_cross(st, bl[:32], bl[32:64])
+ctx.prof_enable(True); ctx.prof_reset()
+t0 = time.perf_counter()
+ctx.bullet_cross(st, bl[:32], bl[32:64])
+dt = time.perf_counter() - t0
+prof = ctx.prof_get(); ctx.prof_enable(False)
+print(f"one cross call {dt * 1e3:.3f} ms (with event timing on); kernels ms:", {k: round(v[0], 4) for k, v in prof.items()})
+st.free(); ta.free(); tb.free(); G.free()

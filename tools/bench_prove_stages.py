@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 5 — the device-side work of one keyless-sized SNARK::prove (Hyrax mode), stage by stage, on synthetic
+tables of the keyless shapes (the keyless R1CS itself is not available offline).  Every stage below is the
+arithmetic the reference does inside the stage of the same name (BENCHMARK_RESULTS.md:35-41), executed through the C ABI with
+the data resident on the device; Fiat-Shamir challenges are SHA3 of the round values (a stand-in for the Merlin transcript,
+which stays in Rust and is strictly sequential either way).
+
+NOT included (host-side control flow that stays in Rust and has no device counterpart here): sparse matrix-vector products
+Az/Bz/Cz and evals_ABC (r1csproof.rs:284-286, 376-387), the per-round Sigma-protocol commitments of the ZK sumchecks
+(sumcheck.rs:539-634: 3-5 point MSMs), DotProductProofLog's final Sigma step, transcript hashing.
+
+Usage: python tools/bench_prove_stages.py [--small]   (--small: all sizes divided by 2^6, for a quick functional check)"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from __graft_entry__ import load_pkg  # noqa: E402
+from conftest import rand_scalars  # noqa: E402
+
+R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+SMALL = "--small" in sys.argv
+SH = 6 if SMALL else 0           # every log-size is reduced by SH in --small mode
+
+
+def main():
+    sbn = load_pkg()
+    ctx = sbn.Context(0)
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    LOG_OPS, LOG_MEM, LOG_CONS = 22 - SH, 21 - SH, 20 - SH
+    stages = {}
+    pool = rand_scalars(1 << 13, 100); pos = [0]
+
+    def scal(k):
+        """k canonical scalars from a pre-generated pool (keeps host-side generation out of the timed regions)"""
+        if pos[0] + k > (1 << 13):
+            pos[0] = 0
+        out = pool[32 * pos[0]:32 * (pos[0] + k)]; pos[0] += k
+        return out
+
+    def rand_table(n):
+        x = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int32, device=dev, generator=gen); x[:, 7] &= 0x0fffffff
+        torch.cuda.synchronize()
+        t = ctx.table_from_dev(x.data_ptr(), n, sbn.SBN_SCALARS_MONT); del x
+        return t
+
+    def challenge(ev):
+        return (int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % R_MOD).to_bytes(32, "little")
+
+    class timed:
+        def __init__(self, name): self.name = name
+        def __enter__(self): ctx.sync(); self.t0 = time.perf_counter()
+        def __exit__(self, *a): ctx.sync(); stages[self.name] = stages.get(self.name, 0.0) + 1e3 * (time.perf_counter() - self.t0)
+
+    def cubic_batched(As, Bs, Cs):
+        """prove_cubic_batched's device work (sumcheck.rs:165-330) to the last round; returns the number of rounds"""
+        tabs = list({id(t): t for t in As + Bs + Cs}.values())
+        n = len(As[0]); rounds = 0
+        if n < 2:
+            return 0
+        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+        while n >= 2:
+            r = challenge(ev); rounds += 1
+            if n >= 4:
+                ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+            else:
+                ctx.bind_top_many(tabs, r)
+            n //= 2
+        return rounds
+
+    def opening(name, Z, log_l, log_r, gens_label):
+        """PolyEvalProof::prove (hyrax.rs:83-160): L*Z, then DotProductProofLog = bullet reduction over the right vector"""
+        n = 1 << log_r
+        with timed(name + ": eq tables + L*Z (bound)"):
+            Lv = ctx.eq_evals(scal(log_l)); Rv = ctx.eq_evals(scal(log_r))
+            LZ = ctx.table_bound(Z, Lv)
+        G, pts = ctx.gens_new(n, gens_label)
+        Q_xy = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+        st, _ = ctx.bullet_begin(G, Q_xy, LZ, Rv, None); ctx.bullet_cross(st); st.free()     # per-circuit setup: derived set G ‖ Q and its window table
+        with timed(name + ": bullet reduction (%d rounds)" % log_r):
+            st, _ = ctx.bullet_begin(G, Q_xy, LZ, Rv, scal(1))
+            for _ in range(log_r):
+                L, _, Rp, _, cL, cR = ctx.bullet_cross(st, scal(1), scal(1))
+                u = challenge(L + Rp); ui = pow(int.from_bytes(u, "little"), R_MOD - 2, R_MOD).to_bytes(32, "little")
+                ctx.bullet_fold(st, u, ui)
+            ctx.bullet_finish(st)
+            st.free()
+        for t in (Lv, Rv, LZ):
+            t.free()
+        G.free()
+
+    # ------------------------------------------------------------------ R1CS satisfiability proof (r1csproof.rs:241-420)
+    wl = LOG_CONS // 2; wr = LOG_CONS - wl
+    gens_w, _ = ctx.gens_new(1 << wr, b"gens_r1cs_sat", want_points=False)
+    z = rand_table(1 << LOG_CONS)
+    wblinds = scal(1 << wl)
+    ctx.commit_table(gens_w, z, wblinds, 1 << wl, 1 << wr)                              # builds the window table once (setup cost of the generator set)
+    with timed("r1cs_sat: witness commit %dx%d" % (1 << wl, 1 << wr)):
+        ctx.commit_table(gens_w, z, wblinds, 1 << wl, 1 << wr)
+    Az, Bz, Cz = (rand_table(1 << LOG_CONS) for _ in range(3))
+    with timed("r1cs_sat: phase-1 sumcheck (4 tables of 2^%d)" % LOG_CONS):
+        tau = ctx.eq_evals(scal(LOG_CONS))
+        ev = ctx.sc_eval_r1cs(tau, Az, Bz, Cz); n = 1 << LOG_CONS
+        while n >= 2:
+            r = challenge(ev)
+            if n >= 4: ev = ctx.sc_bind_eval_r1cs(tau, Az, Bz, Cz, r)
+            else: ctx.bind_top_many([tau, Az, Bz, Cz], r)
+            n //= 2
+    for t in (tau, Az, Bz, Cz): t.free()
+    Zp, ABC = rand_table(2 << LOG_CONS), rand_table(2 << LOG_CONS)
+    with timed("r1cs_sat: phase-2 sumcheck (2 tables of 2^%d)" % (LOG_CONS + 1)):
+        ev = ctx.sc_eval_quad(Zp, ABC); n = 2 << LOG_CONS
+        while n >= 2:
+            r = challenge(ev)
+            if n >= 4: ev = ctx.sc_bind_eval_quad(Zp, ABC, r)
+            else: ctx.bind_top_many([Zp, ABC], r)
+            n //= 2
+    for t in (Zp, ABC): t.free()
+    opening("r1cs_sat: witness opening", z, wl, wr, b"gens_r1cs_sat")
+    z.free(); gens_w.free()
+
+    # ------------------------------------------------------------------ eq tables, derefs, derefs commitment (sparse_mlpoly_full.rs:1713-1727)
+    nops = 1 << LOG_OPS
+    addr = []
+    for k in range(6):
+        a = torch.randint(0, 1 << (LOG_MEM - 1), (nops,), dtype=torch.int32, device=dev, generator=gen); a[int(nops * 0.57):] = 0   # ~43 % padded ops read cell 0 (App. C)
+        addr.append(a)
+    read_ts = [torch.randint(0, 64, (nops,), dtype=torch.int32, device=dev, generator=gen) for _ in range(6)]
+    audit_ts = [torch.randint(0, 64, (1 << LOG_MEM,), dtype=torch.int32, device=dev, generator=gen) for _ in range(2)]
+    torch.cuda.synchronize()
+    dl = (LOG_OPS + 3) // 2; dr = LOG_OPS + 3 - dl
+    gens_d, _ = ctx.gens_new(1 << dr, b"gens_r1cs_eval", want_points=False)
+    warm = rand_table(1 << (dl + dr))
+    ctx.commit_table(gens_d, warm, None, 1 << dl, 1 << dr)                              # builds the window table once (setup cost of the generator set)
+    warm.free()
+    with timed("eq_evals (2 x 2^%d)" % LOG_MEM):
+        mem_rx, mem_ry = ctx.eq_evals(scal(LOG_MEM)), ctx.eq_evals(scal(LOG_MEM))
+    with timed("derefs gather (6 x 2^%d)" % LOG_OPS):
+        comb = ctx.gather_merge([mem_rx] * 3 + [mem_ry] * 3, [a.data_ptr() for a in addr], nops)
+    with timed("derefs commitment %dx%d incl. compression" % (1 << dl, 1 << dr)):
+        out, infs = ctx.commit_table(gens_d, comb, None, 1 << dl, 1 << dr)
+        sbn.g1_compress(out)
+
+    # ------------------------------------------------------------------ network construction (sparse_mlpoly_full.rs:745-796, product_tree.rs:39-57)
+    with timed("network construction (hash layers + 16 product trees)"):
+        g_, tau_ = scal(1), scal(1)
+        ops_circ, mem_circ = [], []
+        for side, mem in enumerate((mem_rx, mem_ry)):
+            mem_circ.append([ctx.hash_layer(None, mem, None, 0, g_, tau_)])                              # init
+            mem_circ.append([ctx.hash_layer(None, mem, audit_ts[side].data_ptr(), 0, g_, tau_)])        # audit
+            for i in range(3):
+                k = 3 * side + i
+                val = ctx.gather_merge([mem], [addr[k].data_ptr()], nops)                                # row/col_ops_val[i]
+                ops_circ.append([ctx.hash_layer(addr[k].data_ptr(), val, read_ts[k].data_ptr(), 0, g_, tau_)])   # read set
+                ops_circ.append([ctx.hash_layer(addr[k].data_ptr(), val, read_ts[k].data_ptr(), 1, g_, tau_)])   # write set
+                val.free()
+        for circ in ops_circ + mem_circ:
+            while len(circ[-1]) > 2:
+                circ.append(ctx.product_layer(circ[-1]))
+
+    # ------------------------------------------------------------------ network proof: batched cubic sumchecks (product_tree.rs:261-340)
+    def layered_proof(name, circs, extra_bottom):
+        rounds = 0
+        nl = len(circs[0])
+        with timed(name):
+            for lay in range(nl - 1, -1, -1):
+                halves = [ctx.table_halves(c[lay]) for c in circs]
+                As, Bs = [h[0] for h in halves], [h[1] for h in halves]
+                k = len(As[0]).bit_length() - 1
+                Cpar = ctx.eq_evals(scal(k)) if k else ctx.table_upload((1).to_bytes(32, "little"))
+                Cs = [Cpar] * len(As)
+                if lay == 0 and extra_bottom:
+                    As, Bs, Cs = As + extra_bottom[0], Bs + extra_bottom[1], Cs + extra_bottom[2]
+                rounds += cubic_batched(As, Bs, Cs)
+                for h in halves:
+                    h[0].free(); h[1].free()
+                Cpar.free()
+        return rounds
+    dotp = [[rand_table(nops // 2) for _ in range(6)] for _ in range(3)]
+    r_ops = layered_proof("network proof: ops product circuits (12 + 6 dotp instances, %d layers)" % len(ops_circ[0]), ops_circ, dotp)
+    r_mem = layered_proof("network proof: mem product circuits (4 instances, %d layers)" % len(mem_circ[0]), mem_circ, None)
+    for grp in dotp:
+        for t in grp: t.free()
+    for circ in ops_circ + mem_circ:
+        for t in circ: t.free()
+
+    # ------------------------------------------------------------------ hash-layer proof: evaluations + the three openings (sparse_mlpoly_full.rs:907-1010)
+    big = [rand_table(nops) for _ in range(3)]
+    with timed("network proof: 23 DensePolynomial::evaluate (18 x 2^%d, 5 x 2^%d)" % (LOG_OPS, LOG_MEM)):
+        for i in range(18): ctx.table_evaluate(big[i % 3], scal(LOG_OPS))
+        for i in range(5): ctx.table_evaluate(mem_rx, scal(LOG_MEM))
+    for t in big: t.free()
+    opening("network proof: derefs opening", comb, dl, dr, b"gens_r1cs_eval")
+    comb.free()
+    ol_ = (LOG_OPS + 4) // 2; or_ = LOG_OPS + 4 - ol_
+    comb_ops = rand_table(1 << (ol_ + or_))
+    opening("network proof: comb_ops opening", comb_ops, ol_, or_, b"gens_r1cs_eval")
+    comb_ops.free()
+    ml = (LOG_MEM + 1) // 2; mr = LOG_MEM + 1 - ml
+    comb_mem = rand_table(1 << (ml + mr))
+    opening("network proof: comb_mem opening", comb_mem, ml, mr, b"gens_r1cs_eval")
+    comb_mem.free()
+    mem_rx.free(); mem_ry.free(); gens_d.free()
+
+    groups = {"r1cs_sat_proof": "r1cs_sat", "eq_evals": "eq_evals", "derefs_gather": "derefs gather", "derefs_commitment": "derefs commitment",
+              "network_construction": "network construction", "network_proof": "network proof"}
+    summary = {g: round(sum(v for k, v in stages.items() if k.startswith(p)), 2) for g, p in groups.items()}
+    summary["total_device_side_ms"] = round(sum(stages.values()), 2)
+    print(json.dumps({"workload": "keyless-shaped prove, device-side stages" + (" (--small: sizes / 2^6)" if SMALL else ""),
+                      "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "summary_ms": summary,
+                      "sumcheck_rounds": {"ops": r_ops, "mem": r_mem},
+                      "reference_published_s_M2Max_1thread": {"r1cs_sat_proof": 3.45, "eq_evals": 0.10, "derefs_gather": 0.14, "derefs_commitment": 166.2,
+                                                              "network_construction": 4.07, "network_proof": 34.5, "total_prove": 208.8},
+                      "note": "published figures include the host-side control flow listed in this tool's docstring; data: synthetic"}, indent=1))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
