@@ -54,7 +54,7 @@ struct sbn_table {
 // synchronises the device and maps / unmaps pages), more than the kernels that fill it, and a prover allocates the same
 // shapes every round.  pool_get returns a cached buffer of at least `bytes` (best fit) or allocates; pool_put keeps up to
 // POOL_MAX_ENTRIES buffers / POOL_MAX_BYTES and releases the rest.
-static const size_t POOL_MAX_ENTRIES = 96;
+static const size_t POOL_MAX_ENTRIES = 1024;   // a keyless-sized prove holds ~300 product-circuit layers + their second buffers
 static const size_t POOL_MAX_BYTES = (size_t)24 << 30;
 static hipError_t pool_get(sbn_ctx* c, size_t bytes, void** out, size_t* got_bytes) {
   if (bytes == 0) bytes = 32;

@@ -24,11 +24,17 @@ static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, siz
   if (env && atoi(env) >= 7 && atoi(env) <= MSM_C_MAX) return make_shape(atoi(env));
   if (cmax > MSM_C_MAX) cmax = MSM_C_MAX;
   if (problems && problems * terms <= 32768) {
+    // expected longest chain ~ mean load + the load of the top window's few buckets (it holds only 254 - (W-1)c bits)
+    double bl = 1e300; int bcl = 7;
     for (int c = 7; c <= cmax; c++) {
       MsmShape s = make_shape(c);
-      const double load = shared_bucket_set ? (double)terms * s.W / s.nb : (double)terms / s.nb;
-      if (load <= 4.0 || c == cmax) return s;
+      const int tb = 254 - (s.W - 1) * c;
+      const double top = (double)terms / (double)(1u << (tb > 0 ? (tb < 20 ? tb : 20) : 0));
+      const double load = (shared_bucket_set ? (double)terms * s.W / s.nb : (double)terms / s.nb) + top;
+      if (load <= 6.0) return s;
+      if (load < bl) { bl = load; bcl = c; }
     }
+    return make_shape(bcl);
   }
   double best = 1e300; int bc = 7;
   // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once

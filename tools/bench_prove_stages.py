@@ -27,9 +27,7 @@ SMALL = "--small" in sys.argv
 SH = 6 if SMALL else 0           # every log-size is reduced by SH in --small mode
 
 
-def main():
-    sbn = load_pkg()
-    ctx = sbn.Context(0)
+def run(sbn, ctx):
     dev = torch.device("cuda:0")
     gen = torch.Generator(device=dev); gen.manual_seed(11)
     LOG_OPS, LOG_MEM, LOG_CONS = 22 - SH, 21 - SH, 20 - SH
@@ -211,7 +209,15 @@ def main():
               "network_construction": "network construction", "network_proof": "network proof"}
     summary = {g: round(sum(v for k, v in stages.items() if k.startswith(p)), 2) for g, p in groups.items()}
     summary["total_device_side_ms"] = round(sum(stages.values()), 2)
-    print(json.dumps({"workload": "keyless-shaped prove, device-side stages" + (" (--small: sizes / 2^6)" if SMALL else ""),
+    return stages, summary, r_ops, r_mem
+
+
+def main():
+    sbn = load_pkg()
+    ctx = sbn.Context(0)
+    run(sbn, ctx)                       # first pass: allocations, window tables, derived generator sets (per-circuit setup)
+    stages, summary, r_ops, r_mem = run(sbn, ctx)
+    print(json.dumps({"workload": "keyless-shaped prove, device-side stages, second pass (buffer cache and generator tables warm, as in a prover that serves many proofs)" + (" (--small: sizes / 2^6)" if SMALL else ""),
                       "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "summary_ms": summary,
                       "sumcheck_rounds": {"ops": r_ops, "mem": r_mem},
                       "reference_published_s_M2Max_1thread": {"r1cs_sat_proof": 3.45, "eq_evals": 0.10, "derefs_gather": 0.14, "derefs_commitment": 166.2,
