@@ -15,13 +15,14 @@ struct sbn_ctx {
   std::string err;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, hist, offs, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
-  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, sc_tickets, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
   hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
   hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
   DevBuf zstage[2], out_rows;
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
+  uint32_t* mbox = nullptr; uint32_t mbox_seq = 0;   // coherent pinned mailbox of the single-launch sumcheck rounds (results + per-instance flags)
   std::vector<std::pair<void*, size_t>> pool; size_t pool_bytes = 0;   // cached table buffers (see pool_get)
   // profiling
   bool prof = false;

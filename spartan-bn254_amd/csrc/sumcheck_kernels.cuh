@@ -36,10 +36,53 @@ __device__ __forceinline__ Fr wave_sum_fr(Fr v) {
   return v;
 }
 
+
+// ---- single-launch rounds -------------------------------------------------------------------------------------------
+// A sumcheck round is a host round trip (the next challenge comes from the transcript), and below ~2^16 entries the trip,
+// not the data, is the cost.  So a round is ONE launch: the table pointers and the challenge travel as kernel arguments (no
+// staging copy), and the last block of every instance to finish — found with a ticket counter — folds the per-block partial
+// sums and stores the canonical values straight into host-visible pinned memory (no finishing kernel, no copy back).
+constexpr int SC_PACK_MAX = 24;            // instances whose pointers fit in the kernel-argument block
+struct ScScalar { uint32_t v[8]; };        // a canonical challenge passed by value
+
+__device__ __forceinline__ Fr fr_load_coherent(const uint32_t* p) {   // written by other blocks of this launch: bypass the CU's L1
+  Fr x;
+#pragma unroll
+  for (int k = 0; k < 8; k++) x.v[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return x;
+}
+// Called by all 256 threads after the block's triple went to partial[(inst * gridDim.x + blockIdx.x) * 3 + q].  nq = 2 or 3.
+// `out` = mailbox in coherent pinned host memory: 24 x 96 B of results, then one flag word per instance; the flag is stored
+// (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
+constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
+__device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
+  __shared__ uint32_t s_last;
+  __threadfence();                         // the triple is visible device-wide before the ticket is taken
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[blockIdx.y], 1u) == gridDim.x - 1) ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wv < 3) {
+    Fr s = fe_zero<FrP>();
+    if (wv < nq) for (unsigned b = lane; b < gridDim.x; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + b) * 3 + wv)));
+    s = wave_sum_fr(s);
+    if (lane == 0) { fe_store<FrP>(out + 8 * ((size_t)blockIdx.y * 3 + wv), fe_from_mont(s)); __threadfence_system(); }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tickets[blockIdx.y] = 0;                          // ready for the next launch
+    __hip_atomic_store(out + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // partial[inst][block][3] (Montgomery form)
+struct ScArgsPack { ScArgs a[SC_PACK_MAX]; };
+// args == nullptr: the instances' pointers are in `pack`; tickets == nullptr: the caller runs k_sc_finish instead of the in-kernel fold
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args, size_t half, uint32_t* __restrict__ partial) {
-  const ScArgs a = args[blockIdx.y];
+__global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args, ScArgsPack pack, size_t half, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
+  const ScArgs a = args ? args[blockIdx.y] : pack.a[blockIdx.y];
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     if (KIND == KIND_QUAD) {
@@ -87,6 +130,7 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
     uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x);
     for (int k = 0; k < 8; k++) o[k] = s.v[k];
   }
+  if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
 // Fused round: bind every table to r_j (hyrax.rs:195-203) AND accumulate the round-(j+1) sums from the freshly bound
@@ -98,10 +142,13 @@ struct ScFusedArgs {
   const uint32_t* src[4];
   uint32_t* dst[4];
 };
+struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, size_t q /* old_len / 4 */, const uint32_t* __restrict__ rm, uint32_t* __restrict__ partial) {
-  const ScFusedArgs a = args[blockIdx.y];
-  const Fr r = fe_load<FrP>(rm);
+__global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rc /* canonical */, uint32_t* __restrict__ partial,
+                                                      uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
+  const ScFusedArgs a = args ? args[blockIdx.y] : pack.a[blockIdx.y];
+  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rc.v[k];
+  r = fe_to_mont(r);
   constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
@@ -146,6 +193,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restr
     uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x);
     for (int k = 0; k < 8; k++) o[k] = s.v[k];
   }
+  if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
 // out[inst][3] canonical; one 64-lane block per instance folds `nblk` partial triples

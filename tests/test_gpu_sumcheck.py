@@ -316,3 +316,28 @@ def test_network_construction_pieces(ctx, ol, pr):
         t.free()
     for p in (d_addr, d_ts, d_au):
         ctx.dev_free(p)
+
+
+@pytest.mark.parametrize("count", [24, 25, 40])
+def test_many_instances_both_launch_paths(ctx, ol, count):
+    """up to 24 instances travel as kernel arguments and are folded by the last block (one launch per round); more use the staged
+    argument array + finishing kernel.  Both must give the oracle's values, repeatedly (the ticket counters reset themselves)."""
+    n = 256
+    tabs = [rand_scalars(n, 900 + i) for i in range(count + 2)]
+    dev = [ctx.table_upload(x) for x in tabs]
+    idx = [(i, i + 1, i + 2) for i in range(count)]
+    As, Bs, Cs = ([dev[t[k]] for t in idx] for k in range(3))
+    want = b"".join(ol.sc_eval_cubic(tabs[a], tabs[b], tabs[c]) for a, b, c in idx)
+    for _ in range(3):
+        assert ctx.sc_eval_cubic_batched(As, Bs, Cs) == want
+    r = rand_scalars(1, 77)
+    bound = [ol.bind_top(x, r) for x in tabs]
+    want2 = b"".join(ol.sc_eval_cubic(bound[a], bound[b], bound[c]) for a, b, c in idx)
+    assert ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r) == want2
+    for t, h in zip(dev, bound):
+        assert ctx.table_download(t) == h
+    r2 = rand_scalars(1, 78)
+    bound2 = [ol.bind_top(x, r2) for x in bound]
+    assert ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r2) == b"".join(ol.sc_eval_cubic(bound2[a], bound2[b], bound2[c]) for a, b, c in idx)
+    for t in dev:
+        t.free()
