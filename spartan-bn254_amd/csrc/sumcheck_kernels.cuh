@@ -82,7 +82,13 @@ struct ScArgsPack { ScArgs a[SC_PACK_MAX]; };
 // args == nullptr: the instances' pointers are in `pack`; tickets == nullptr: the caller runs k_sc_finish instead of the in-kernel fold
 template <int KIND>
 __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args, ScArgsPack pack, size_t half, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
-  const ScArgs a = args ? args[blockIdx.y] : pack.a[blockIdx.y];
+  ScArgs a;
+  if (args) a = args[blockIdx.y];
+  else {
+    // statically indexed selects: a dynamic index into a by-value argument would make the compiler copy the whole block to scratch
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
+  }
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     if (KIND == KIND_QUAD) {
@@ -146,7 +152,12 @@ struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
 template <int KIND>
 __global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rc /* canonical */, uint32_t* __restrict__ partial,
                                                       uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
-  const ScFusedArgs a = args ? args[blockIdx.y] : pack.a[blockIdx.y];
+  ScFusedArgs a;
+  if (args) a = args[blockIdx.y];
+  else {
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
+  }
   Fr r; for (int k = 0; k < 8; k++) r.v[k] = rc.v[k];
   r = fe_to_mont(r);
   constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
