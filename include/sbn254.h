@@ -211,6 +211,9 @@ int sbn_prof_reset(sbn_ctx* ctx);
 /* number of distinct kernel names seen; i-th name, summed ms and launch count */
 int sbn_prof_count(sbn_ctx* ctx);
 int sbn_prof_get(sbn_ctx* ctx, int i, const char** name, double* total_ms, uint64_t* launches);
+/* shape of the context's most recent bucket job (an MSM or a row commit): out = {window bits c, windows W, (digit, point)
+ * slots = mixed additions when no digit is zero, buckets}; bench.py prices the accumulate kernel against the ALU roofline with it */
+int sbn_prof_last_job(sbn_ctx* ctx, uint64_t out[4]);
 
 #ifdef __cplusplus
 }

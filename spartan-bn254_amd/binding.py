@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -380,6 +380,11 @@ class Context:
     # ---- profiling
     def prof_enable(self, on=True):
         self._chk(lib().sbn_prof_enable(self.h, int(on)), "prof_enable")
+
+    def prof_last_job(self):
+        """{c, W, slots, buckets} of the most recent MSM / row commit on this context"""
+        o = (C.c_uint64 * 4)(); self._chk(lib().sbn_prof_last_job(self.h, o), "prof_last_job")
+        return {"c": int(o[0]), "W": int(o[1]), "slots": int(o[2]), "buckets": int(o[3])}
 
     def prof_reset(self):
         self._chk(lib().sbn_prof_reset(self.h), "prof_reset")

@@ -24,6 +24,7 @@ struct sbn_ctx {
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
   uint32_t* mbox = nullptr; uint32_t mbox_seq = 0;   // coherent pinned mailbox of the single-launch sumcheck rounds (results + per-instance flags)
   std::vector<std::pair<void*, size_t>> pool; size_t pool_bytes = 0;   // cached table buffers (see pool_get)
+  uint64_t last_job[4] = {0, 0, 0, 0};      // window bits, windows, (digit, point) slots, buckets of the most recent bucket job
   // profiling
   bool prof = false;
   std::vector<ProfEntry> prof_entries;

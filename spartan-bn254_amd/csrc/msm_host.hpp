@@ -63,6 +63,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const size_t NB = J.P * (size_t)s.nb;
   if (NB > 0xffffffffull) return fail(c, SBN_EINVAL, "bucket space too large");
   const size_t estride = J.da.estride;
+  c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(J.P * estride); c->last_job[3] = (uint64_t)NB;
   // segment length: twice the mean bucket load (power of two, >= 32)
   size_t mean = estride / (size_t)s.nb + 1;
   uint32_t SEG = 32; while (SEG < 2 * mean && SEG < ACC_SEG_MAX) SEG <<= 1;

@@ -45,5 +45,11 @@ int sbn_prof_get(sbn_ctx* c, int i, const char** name, double* total_ms, uint64_
   if (launches) *launches = c->prof_entries[i].launches;
   return SBN_OK;
 }
+int sbn_prof_last_job(sbn_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return SBN_EINVAL;
+  std::lock_guard<std::mutex> g(c->mu);
+  for (int i = 0; i < 4; i++) out[i] = c->last_job[i];
+  return SBN_OK;
+}
 
 }  // extern "C"
