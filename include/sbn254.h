@@ -70,6 +70,12 @@ int sbn_msm_jacobian(sbn_ctx* ctx, const uint8_t* scalars, const uint8_t* points
 int sbn_bases_upload(sbn_ctx* ctx, const uint8_t* G_xy, size_t n, const uint8_t* h_xy, uint32_t flags, sbn_bases** out);
 void sbn_bases_free(sbn_ctx* ctx, sbn_bases* b);
 size_t sbn_bases_len(const sbn_bases* b);          /* n (without h) */
+/* Fixed-base precomputation for a generator set that will serve many commitments (the per-circuit gens_derefs / gens_ops of
+ * SparseMatPolyCommitmentGens, sparse_mlpoly_full.rs:619-627): a table of every digit multiple d * 2^(c w) * G_j in HBM, so a row
+ * commitment costs ceil(254/c) mixed additions per scalar and no bucket work.  The largest window c <= 16 whose table fits
+ * max_bytes is built (the reference's 8193 gens_r1cs_eval generators: 2814 unique x 16 windows x 32768 x 64 B = 94 GB at c = 16);
+ * commits on this handle use it from then on.  Results are unchanged (same group element).  *window_bits (optional) <- c. */
+int sbn_bases_precompute(sbn_ctx* ctx, sbn_bases* b, size_t max_bytes, int* window_bits);
 /* MultiCommitGens::new(n, label) (commitments.rs:31-62): SHAKE256 stream -> from_uniform_bytes (group.rs:110-131);
  * builds G[0..n) and h on the device and, if out_xy != NULL, also returns the n+1 canonical points. */
 int sbn_gens_new(sbn_ctx* ctx, size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, sbn_bases** out);

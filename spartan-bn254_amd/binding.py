@@ -10,7 +10,7 @@ SBN_POINTS_MONT = 2
 EXPORTED_SYMBOLS = [
     "sbn_ctx_create", "sbn_ctx_destroy", "sbn_last_error", "sbn_ctx_set_stream", "sbn_ctx_sync", "sbn_version",
     "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
-    "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_bases_download",
+    "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_precompute", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_bases_download",
     "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_unipoly_from_evals", "sbn_unipoly_eval", "sbn_factored_lens",
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
@@ -199,6 +199,12 @@ class Context:
         out = (C.c_uint8 * 64)(); inf = C.c_int()
         self._chk(lib().sbn_msm_jacobian(self.h, _ptr(scalars), _ptr(points_xyz), C.c_size_t(n), C.c_uint32(flags), out, C.byref(inf)), "sbn_msm_jacobian")
         return bytes(out), bool(inf.value)
+
+    def bases_precompute(self, bases, max_bytes):
+        """build the fixed-base lookup table within max_bytes of HBM; returns the window bits chosen"""
+        cw = C.c_int(0)
+        self._chk(lib().sbn_bases_precompute(self.h, bases.h, C.c_size_t(max_bytes), C.byref(cw)), "sbn_bases_precompute")
+        return cw.value
 
     def bases_split_at(self, bases, mid):
         l, r = C.c_void_p(), C.c_void_p()

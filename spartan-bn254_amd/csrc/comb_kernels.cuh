@@ -1,0 +1,92 @@
+// comb_kernels.cuh — fixed-base direct lookup for the Hyrax row commits (hyrax.rs:253-267 over a fixed MultiCommitGens).
+//
+// The generators of a commitment key never change, and an MI355X has 288 GB of HBM.  So beyond the window table
+// 2^(c w) * G_j the key can hold EVERY digit multiple:  T[w][j][d-1] = d * 2^(c w) * G_j,  d = 1 .. 2^(c-1)  (affine,
+// Montgomery, 64 B; negative digits negate y).  A row commitment is then sum_j sum_w (+-)T[w][j][|d_jw|]: W mixed additions
+// per scalar into one accumulator — no buckets, no sort, no bucket reduction, and therefore no reason to keep c small:
+// at c = 16 a 254-bit scalar costs 16 mixed additions instead of the 24 the bucket method's optimum (c = 11) needs for the
+// 2813 unique reference generators.  The table for that set is 2814 x 16 x 32768 x 64 B = 94 GB; random 64-byte gathers
+// from a table of that size run at 1.9e10 /s on MI355X (tools/micro/gather.hip), above the 1.2e10 /s mixed-addition ceiling.
+#pragma once
+#include "msm_kernels.cuh"
+
+namespace sbn {
+
+constexpr int COMB_CH = 64;      // multiples per lane in the table build (one batched inversion per lane)
+
+// One window slab of the table.  Lane t -> (column j, chunk a): entries d = 64 a + 1 .. 64 a + 64 of column j.
+// tmp_xyzz / tmp_pref: COMB_CH x lanes records (k-major, so a wave's accesses are contiguous).
+__global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ wtab /* this window's npts affine points */, size_t npts, int c, size_t lane0, size_t lanes,
+                                                   uint32_t* __restrict__ tmp_xyzz, uint32_t* __restrict__ tmp_pref, uint32_t* __restrict__ slab /* npts << (c-1) affine */) {
+  const size_t tl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tl >= lanes) return;
+  const size_t t = lane0 + tl;
+  const size_t A = ((size_t)1 << (c - 1)) / COMB_CH;
+  const size_t j = t / A, a = t - j * A;
+  const Affine P = aff_load(wtab + 16 * j);
+  uint32_t* dst = slab + 16 * ((j << (c - 1)) + a * COMB_CH);
+  if (aff_is_inf(P)) {                                   // a generator at infinity: all its multiples are
+    const Affine z = P;
+    for (int k = 0; k < COMB_CH; k++) aff_store(dst + 16 * k, z);
+    return;
+  }
+  // Q = (64 a) * P, then 64 mixed additions
+  XYZZ Q = xyzz_inf();
+  const uint32_t m0 = (uint32_t)(a * COMB_CH);
+  for (int b = 15; b >= 0; b--) {
+    Q = xyzz_dbl(Q);
+    if ((m0 >> b) & 1u) xyzz_madd(Q, P, false);
+  }
+  Fq run = fe_one<FqP>();
+  for (int k = 0; k < COMB_CH; k++) {
+    xyzz_madd(Q, P, false);                              // (64 a + k + 1) * P: never infinity (prime order, multiplier < r)
+    xyzz_store(tmp_xyzz + 32 * ((size_t)k * lanes + tl), Q);
+    run = fe_mul(run, fe_mul(Q.ZZ, Q.ZZZ));
+    fe_store<FqP>(tmp_pref + 8 * ((size_t)k * lanes + tl), run);
+  }
+  Fq inv = fe_inv(run);
+  for (int k = COMB_CH - 1; k >= 0; k--) {
+    const XYZZ E = xyzz_load(tmp_xyzz + 32 * ((size_t)k * lanes + tl));
+    const Fq prev = k ? fe_load<FqP>(tmp_pref + 8 * ((size_t)(k - 1) * lanes + tl)) : fe_one<FqP>();
+    const Fq I = fe_mul(inv, prev);                      // 1 / (ZZ_k * ZZZ_k)
+    inv = fe_mul(inv, fe_mul(E.ZZ, E.ZZZ));
+    Affine o; o.x = fe_mul(E.X, fe_mul(I, E.ZZZ)); o.y = fe_mul(E.Y, fe_mul(I, E.ZZ));
+    aff_store(dst + 16 * k, o);
+  }
+}
+
+// Row commits by lookup.  grid = (rows, S): S blocks share a row (few rows: keep the chip busy, keep chains short); lane tid of
+// block (row, s) sums the columns col = s*256 + tid, + 256 S, ... and stores its accumulator to partial[(row*S + s)*256 + tid].
+// The kernel is nothing but the accumulate loop (the tree sum lives in k_comb_fold: keeping it out holds this kernel at the
+// register budget of the bucket accumulate kernel, 3 waves per SIMD instead of 2).
+__global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ skip, uint32_t* __restrict__ partial) {
+  const size_t row = blockIdx.x; const unsigned S = gridDim.y;
+  XYZZ acc = xyzz_inf();
+  if (!(skip && skip[row] == 2)) {
+    Affine p_prev; bool neg_prev = false, have = false;
+    for (size_t col = (size_t)blockIdx.y * blockDim.x + threadIdx.x; col < a.n; col += (size_t)S * blockDim.x) {
+      const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      uint32_t carry = 0;
+      for (int w = 0; w < s.W; w++) {
+        const int d = window_digit(k, w, s.c, carry);
+        if (d == 0) continue;
+        const size_t idx = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
+        const Affine p = aff_load(table + 16 * idx);     // in flight during the previous point's mixed addition
+        if (have) xyzz_madd(acc, p_prev, neg_prev);
+        p_prev = p; neg_prev = d < 0; have = true;
+      }
+    }
+    if (have) xyzz_madd(acc, p_prev, neg_prev);
+  }
+  xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc);
+}
+// per row: `per_row` lane accumulators -> out[row]; one wave per row
+__global__ void __launch_bounds__(64) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out) {
+  const size_t row = blockIdx.x; const int lane = threadIdx.x;
+  XYZZ v = xyzz_inf();
+  for (unsigned i = lane; i < per_row; i += 64) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
+  v = wave_sum(v, lane);
+  if (lane == 0) xyzz_store(out + 32 * row, v);
+}
+
+}  // namespace sbn

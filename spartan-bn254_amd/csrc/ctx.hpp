@@ -18,7 +18,7 @@ struct sbn_ctx {
   DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, sc_tickets, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
   hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
   hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
-  DevBuf zstage[2], out_rows;
+  DevBuf zstage[2], out_rows, comb_partial;
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
@@ -41,6 +41,8 @@ struct sbn_bases {
   sbn_bases* uniq = nullptr;
   size_t U = 0; uint32_t nbig = 0; uint32_t hcol = 0;   // hcol: the unique base h maps to
   void* d_csr_off = nullptr; void* d_csr_cols = nullptr; void* d_big = nullptr;
+  // fixed-base direct-lookup table (comb_kernels.cuh): W x npts x 2^(c-1) affine points, built by sbn_bases_precompute
+  void* d_comb = nullptr; int comb_c = 0; size_t comb_bytes = 0;
   // bullet reduction (abi_bullet.inc): derived sets G ‖ Q (+ h), one per distinct Q, built on first use and owned by this handle
   mutable std::vector<std::pair<std::string, sbn_bases*>> bullet_ext;
 };

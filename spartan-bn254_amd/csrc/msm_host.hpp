@@ -203,6 +203,51 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
   return SBN_OK;
 }
 
+// Direct-lookup table of a generator set (comb_kernels.cuh): the largest window c <= 16 whose table fits `max_bytes`.
+static int bases_build_comb(sbn_ctx* c, sbn_bases* b, size_t max_bytes) {
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  if (npts == 0) return fail(c, SBN_EINVAL, "precompute: empty generator set");
+  int cc = 0; size_t bytes = 0;
+  for (int t = MSM_C_MAX; t >= 7; t--) {
+    const MsmShape s = make_shape(t);
+    const size_t need = npts * (size_t)s.W * (size_t)s.nb * 64;
+    if (need <= max_bytes) { cc = t; bytes = need; break; }
+  }
+  if (!cc) return fail(c, SBN_EINVAL, "precompute: even the c = 7 table (%zu B) exceeds the budget of %zu B", npts * (size_t)make_shape(7).W * 64 * 64, max_bytes);
+  {
+    std::lock_guard<std::mutex> tg(g_bases_tables_mu);
+    if (b->d_comb && b->comb_c == cc) return SBN_OK;
+  }
+  const MsmShape s = make_shape(cc);
+  int rc; const uint32_t* wtab;
+  if ((rc = bases_window_table(c, b, s, &wtab))) return rc;
+  std::lock_guard<std::mutex> tg(g_bases_tables_mu);
+  if (b->d_comb) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(b->d_comb); b->d_comb = nullptr; b->comb_c = 0; }
+  void* tab = nullptr;
+  hipError_t e = hipMalloc(&tab, bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, SBN_ENOMEM, "hipMalloc lookup table (%zu B): %s", bytes, hipGetErrorString(e)); }
+  const size_t slab_lanes = npts * ((size_t)s.nb / COMB_CH);
+  const size_t BL = std::min<size_t>(slab_lanes, (size_t)1 << 18);
+  void* tx = nullptr; void* tp = nullptr;
+  if ((e = hipMalloc(&tx, BL * COMB_CH * 128)) != hipSuccess || (e = hipMalloc(&tp, BL * COMB_CH * 32)) != hipSuccess) {
+    (void)hipGetLastError(); hipFree(tab); if (tx) hipFree(tx);
+    return fail(c, SBN_ENOMEM, "hipMalloc lookup-table build scratch: %s", hipGetErrorString(e));
+  }
+  for (int w = 0; w < s.W; w++)
+    for (size_t l0 = 0; l0 < slab_lanes; l0 += BL) {
+      const size_t lanes = std::min(BL, slab_lanes - l0);
+      LAUNCH(c, "k_comb_build", k_comb_build, (unsigned)((lanes + 63) / 64), 64, wtab + 16 * ((size_t)w * npts), npts, cc, l0, lanes, (uint32_t*)tx, (uint32_t*)tp,
+             (uint32_t*)tab + 16 * (((size_t)w * npts) << (cc - 1)));
+    }
+  hipError_t le = hipGetLastError();
+  hipError_t se = hipStreamSynchronize(c->stream);
+  hipFree(tx); hipFree(tp);
+  if (le != hipSuccess || se != hipSuccess) { hipFree(tab); return fail(c, SBN_EHIP, "lookup-table build: %s", hipGetErrorString(le != hipSuccess ? le : se)); }
+  if (c->prof) prof_drain(c);
+  b->d_comb = tab; b->comb_c = cc; b->comb_bytes = bytes;
+  return SBN_OK;
+}
+
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
 // launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
 // (d_xy == nullptr: stop before the conversion and leave the L sums as XYZZ in c->wsum)
@@ -225,9 +270,28 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if (!d_xy) { int rc0; if ((rc0 = ensure(c, c->wsum, L * 128))) return rc0; HIPCHK(c, hipMemsetAsync(c->wsum.p, 0, L * 128, c->stream)); return SBN_OK; }
     HIPCHK(c, hipMemsetAsync(d_xy, 0, 64 * L, c->stream)); HIPCHK(c, hipMemsetAsync(d_inf, 1, L, c->stream)); return SBN_OK;
   }
+  const size_t npts = b->n + (b->has_h ? 1 : 0);
+  if (b->d_comb) {
+    // fixed-base lookup: W mixed additions per scalar, no buckets (comb_kernels.cuh)
+    const MsmShape s = make_shape(b->comb_c);
+    DigitArgs da; memset(&da, 0, sizeof da);
+    da.scalars = dZ; da.blinds = dBl; da.n = ncol; da.R = R; da.L = L; da.tstride = npts;
+    unsigned S = 1; while ((size_t)L * S < 2048 && S < 16 && (size_t)S * 256 < ncol) S <<= 1;
+    if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = (unsigned)v; }
+    int rc;
+    if ((rc = ensure(c, c->wsum, L * 128))) return rc;
+    if ((rc = ensure(c, c->comb_partial, L * S * 256 * 128))) return rc;
+    if (L > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: too many rows");
+    c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(L * ncol * (size_t)s.W); c->last_job[3] = 0;
+    LAUNCH(c, "k_comb_rows", k_comb_rows, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
+    LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S * 256u, (uint32_t*)c->wsum.p);
+    if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));
+    if (d_xy) LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
+    LAUNCHCHK(c);
+    return SBN_OK;
+  }
   BucketJob J; memset(&J, 0, sizeof J);
   J.mode = MODE_ROWS; J.s = choose_shape(ncol, true, 16, L); J.P = L; J.threads = L * ncol;
-  const size_t npts = b->n + (b->has_h ? 1 : 0);
   if ((size_t)J.s.W * npts > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: table index overflow");
   int rc; const uint32_t* tab;
   if ((rc = bases_window_table(c, b, J.s, &tab))) return rc;

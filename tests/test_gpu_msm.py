@@ -459,5 +459,57 @@ def test_hyrax_derefs_shape_properties(ctx, ol, pr):
         # rows are independent: a 2-row slice gives the same commitments (row-sharded multi-GPU path)
         o2, _ = ctx.commit_rows_dev(bases, Z.data_ptr() + 32 * R * 1000, 0, 2, R)
         assert o2 == out[64 * 1000:64 * 1002]
+        # fixed-base lookup table in HBM (sbn_bases_precompute): a different algorithm (no buckets), the same 4096 points
+        cw = ctx.bases_precompute(bases, 100 << 30)
+        assert 13 <= cw <= 16
+        out3, infs3 = ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, R)
+        assert out3 == out and infs3 == infs
+        o4, _ = ctx.commit_rows_dev(bases, Z.data_ptr() + 32 * R * 1000, 0, 2, R)       # few rows: several blocks per row
+        assert o4 == out[64 * 1000:64 * 1002]
     finally:
         bases.free()
+
+
+@pytest.mark.parametrize("R,label,budget_mb", [(64, b"gens_r1cs_eval", 8), (100, b"distinct", 64), (1024, b"gens_r1cs_sat", 512)])
+def test_commit_rows_with_lookup_table_vs_oracle(ctx, ol, pr, R, label, budget_mb):
+    """sbn_bases_precompute: every row commitment by table lookup must equal the oracle's (and the bucket path's), with and
+    without blinds, for zero / constant / ordinary rows and edge scalars, at several row counts (1 block .. 16 blocks per row)."""
+    gx, _ = ol.gens_new(R, label)
+    if label == b"distinct":                      # all-distinct bases: no merged columns
+        gx = ol.g1_mul_gen_batch(rand_scalars(R + 1, 4242))
+    b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+    try:
+        for L in (1, 2, 9, 40):
+            Z = bytearray(rand_scalars(L * R, L * 13 + R))
+            if L >= 9:
+                Z[32 * R:64 * R] = bytes(32 * R)                                  # zero row
+                Z[64 * R:96 * R] = Z[64 * R:64 * R + 32] * R                      # constant row
+                edge = [0, 1, pr.R - 1, pr.R - 2, 1 << 253, (1 << 128) - 1, 1 << 15, (1 << 16) - 1]
+                Z[96 * R:96 * R + 32 * len(edge)] = b"".join(pr.scalar_to_bytes(v) for v in edge)
+            Z = bytes(Z); bl = rand_scalars(L, 5 + L)
+            want_b = ol.commit_rows(Z, bl, L, R, gx[:64 * R], gx[64 * R:], 16)
+            want_0 = ol.commit_rows(Z, None, L, R, gx[:64 * R], gx[64 * R:], 16)
+            if L == 1:
+                before = ctx.commit_rows(b, Z, bl, L, R)[0]
+                assert before == want_b
+                cw = ctx.bases_precompute(b, budget_mb << 20)
+                assert 7 <= cw <= 16
+            assert ctx.commit_rows(b, Z, bl, L, R)[0] == want_b, (L, "blinds")
+            out, infs = ctx.commit_rows(b, Z, None, L, R)
+            assert out == want_0, (L, "no blinds")
+            if L >= 9:
+                assert infs[1] == 1
+    finally:
+        b.free()
+
+
+def test_precompute_budget_errors(ctx, ol, sbn):
+    gx, _ = ol.gens_new(16, b"x")
+    b = ctx.bases_upload(gx[:64 * 16], gx[64 * 16:])
+    try:
+        with pytest.raises(sbn.SbnError):
+            ctx.bases_precompute(b, 1024)             # not even the smallest table fits
+        assert ctx.bases_precompute(b, 1 << 20) >= 7
+        assert ctx.bases_precompute(b, 1 << 20) >= 7  # idempotent
+    finally:
+        b.free()

@@ -96,6 +96,8 @@ def run(sbn, ctx):
     wl = LOG_CONS // 2; wr = LOG_CONS - wl
     gens_w, _ = ctx.gens_new(1 << wr, b"gens_r1cs_sat", want_points=False)
     z = rand_table(1 << LOG_CONS)
+    if not SMALL:
+        ctx.bases_precompute(gens_w, 16 << 30)                                           # per-circuit setup: fixed-base lookup table (11.7 GB)
     wblinds = scal(1 << wl)
     ctx.commit_table(gens_w, z, wblinds, 1 << wl, 1 << wr)                              # builds the window table once (setup cost of the generator set)
     with timed("r1cs_sat: witness commit %dx%d" % (1 << wl, 1 << wr)):
@@ -133,6 +135,8 @@ def run(sbn, ctx):
     torch.cuda.synchronize()
     dl = (LOG_OPS + 3) // 2; dr = LOG_OPS + 3 - dl
     gens_d, _ = ctx.gens_new(1 << dr, b"gens_r1cs_eval", want_points=False)
+    if not SMALL:
+        ctx.bases_precompute(gens_d, 100 << 30)                                          # per-circuit setup: 94 GB lookup table of gens_derefs
     warm = rand_table(1 << (dl + dr))
     ctx.commit_table(gens_d, warm, None, 1 << dl, 1 << dr)                              # builds the window table once (setup cost of the generator set)
     warm.free()
