@@ -80,13 +80,22 @@ __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ 
   }
   xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc);
 }
-// per row: `per_row` lane accumulators -> out[row]; one wave per row
-__global__ void __launch_bounds__(64) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out) {
-  const size_t row = blockIdx.x; const int lane = threadIdx.x;
+// per row: `per_row` lane accumulators -> out[row].  One block per row: strided partial sums, wave tree, and — when the block has
+// four waves (many accumulators per row, i.e. few rows) — an LDS step across them.  Many rows use one wave per row.
+__global__ void __launch_bounds__(256) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out) {
+  const size_t row = blockIdx.x; const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __shared__ uint32_t sm[4][32];
   XYZZ v = xyzz_inf();
-  for (unsigned i = lane; i < per_row; i += 64) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
+  for (unsigned i = threadIdx.x; i < per_row; i += blockDim.x) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
   v = wave_sum(v, lane);
-  if (lane == 0) xyzz_store(out + 32 * row, v);
+  if (blockDim.x == 64) { if (lane == 0) xyzz_store(out + 32 * row, v); return; }
+  if (lane == 0) xyzz_store(sm[wv], v);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ t = xyzz_load(sm[0]);
+    for (int w = 1; w < 4; w++) t = xyzz_add(t, xyzz_load(sm[w]));
+    xyzz_store(out + 32 * row, t);
+  }
 }
 
 }  // namespace sbn
