@@ -59,6 +59,9 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
 // block (row, s) sums the columns col = s*256 + tid, + 256 S, ... and stores its accumulator to partial[(row*S + s)*256 + tid].
 // The kernel is nothing but the accumulate loop (the tree sum lives in k_comb_fold: keeping it out holds this kernel at the
 // register budget of the bucket accumulate kernel, 3 waves per SIMD instead of 2).
+// BLOCKSUM (few rows, latency-bound: occupancy is irrelevant): the block also tree-sums its 256 accumulators and stores ONE point
+// to partial[row*S + s], which leaves k_comb_fold a handful of points per row instead of thousands.
+template <bool BLOCKSUM>
 __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ skip, uint32_t* __restrict__ partial) {
   const size_t row = blockIdx.x; const unsigned S = gridDim.y;
   XYZZ acc = xyzz_inf();
@@ -78,7 +81,17 @@ __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ 
     }
     if (have) xyzz_madd(acc, p_prev, neg_prev);
   }
-  xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc);
+  if (!BLOCKSUM) { xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc); return; }
+  __shared__ uint32_t sm[4][32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  acc = wave_sum(acc, lane);
+  if (lane == 0) xyzz_store(sm[wv], acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    XYZZ t = xyzz_load(sm[0]);
+    for (int w = 1; w < 4; w++) t = xyzz_add(t, xyzz_load(sm[w]));
+    xyzz_store(partial + 32 * (row * S + blockIdx.y), t);
+  }
 }
 // per row: `per_row` lane accumulators -> out[row].  One block per row: strided partial sums, wave tree, and — when the block has
 // four waves (many accumulators per row, i.e. few rows) — an LDS step across them.  Many rows use one wave per row.

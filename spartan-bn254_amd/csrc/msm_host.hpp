@@ -283,8 +283,13 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if ((rc = ensure(c, c->comb_partial, L * S * 256 * 128))) return rc;
     if (L > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: too many rows");
     c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(L * ncol * (size_t)s.W); c->last_job[3] = 0;
-    LAUNCH(c, "k_comb_rows", k_comb_rows, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
-    LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, S > 1 ? 256 : 64, (const uint32_t*)c->comb_partial.p, S * 256u, (uint32_t*)c->wsum.p);
+    if (S > 1) {      // few rows: latency-bound, sum inside the block
+      LAUNCH(c, "k_comb_rows", k_comb_rows<true>, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
+      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p);
+    } else {
+      LAUNCH(c, "k_comb_rows", k_comb_rows<false>, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
+      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, 256u, (uint32_t*)c->wsum.p);
+    }
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));
     if (d_xy) LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
     LAUNCHCHK(c);
