@@ -157,6 +157,10 @@ int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
 int sbn_table_dot(sbn_ctx* ctx, const sbn_table* a, const sbn_table* b, uint8_t out[32]);
 /* DensePolynomial::evaluate(r) (hyrax.rs:217-222) = <Z, eq(r)>; the eq table is built on the device (r: ell scalars, 2^ell == len) */
 int sbn_table_evaluate(sbn_ctx* ctx, const sbn_table* Z, const uint8_t* r, size_t ell, uint8_t out[32]);
+/* the same for `count` tables of equal length at ONE point: HashLayerProof::prove evaluates 6 derefs + 15 addr/val/ts polynomials at
+ * rand_ops and 2 at rand_mem (sparse_mlpoly_full.rs:907-976), each call rebuilding the eq table in the reference; here it is built once.
+ * out = count x 32 B */
+int sbn_table_evaluate_many(sbn_ctx* ctx, const sbn_table* const* Z, size_t count, const uint8_t* r, size_t ell, uint8_t* out);
 /* DensePolynomial::bound(L) (hyrax.rs:311-324), the L*Z of PolyEvalProof::prove (hyrax.rs:101): Z viewed as L_size x R_size,
  * out[i] = sum_j Lvec[j] * Z[j*R_size + i]  (a new table of R_size entries) */
 int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn_table** out);

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -344,6 +344,11 @@ class Context:
 
     def table_evaluate(self, Z, r):
         out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_evaluate(self.h, Z.h, _ptr(r), C.c_size_t(len(r) // 32), out), "sbn_table_evaluate"); return bytes(out)
+
+    def table_evaluate_many(self, Zs, r):
+        k = len(Zs); arr = (C.c_void_p * k)(*[t.h for t in Zs]); out = (C.c_uint8 * (32 * k))()
+        self._chk(lib().sbn_table_evaluate_many(self.h, arr, C.c_size_t(k), _ptr(r), C.c_size_t(len(r) // 32), out), "sbn_table_evaluate_many")
+        return bytes(out)
 
     def table_bound(self, Z, Lvec):
         ht = C.c_void_p(); self._chk(lib().sbn_table_bound(self.h, Z.h, Lvec.h, C.byref(ht)), "sbn_table_bound"); return Table(self, ht)

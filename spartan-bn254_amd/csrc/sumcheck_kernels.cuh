@@ -270,9 +270,10 @@ __global__ void __launch_bounds__(256) k_product_layer(const uint32_t* __restric
     fe_store<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
 }
 // g (canonical) -> {mont(g), g^2 * R^2 mod r (= mont(mont(g^2))), mont(tau)}
-__global__ void k_hash_consts(const uint32_t* __restrict__ g_tau_canon, uint32_t* __restrict__ consts) {
+__global__ void k_hash_consts(ScScalar g_canon, ScScalar tau_canon, uint32_t* __restrict__ consts) {
   if (threadIdx.x || blockIdx.x) return;
-  const Fr gm = fe_to_mont(fe_load<FrP>(g_tau_canon)), tm = fe_to_mont(fe_load<FrP>(g_tau_canon + 8));
+  Fr g, t; for (int k = 0; k < 8; k++) { g.v[k] = g_canon.v[k]; t.v[k] = tau_canon.v[k]; }
+  const Fr gm = fe_to_mont(g), tm = fe_to_mont(t);
   fe_store<FrP>(consts, gm);
   fe_store<FrP>(consts + 8, fe_to_mont(fe_mul(gm, gm)));
   fe_store<FrP>(consts + 16, tm);
@@ -293,6 +294,27 @@ __global__ void __launch_bounds__(256) k_dot(const uint32_t* __restrict__ a, con
     for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
     // stored in the 3-slot layout of k_sc_finish (slots 1, 2 zero)
     uint32_t* o = partial + 8 * ((size_t)blockIdx.x * 3);
+    for (int k = 0; k < 8; k++) { o[k] = s.v[k]; o[8 + k] = 0; o[16 + k] = 0; }
+  }
+}
+// <Z_i, chi> for up to SC_PACK_MAX tables at once (blockIdx.y = table): the evaluations of many polynomials at one point
+__global__ void __launch_bounds__(256) k_dot_many(ScArgsPack pack, const uint32_t* __restrict__ chi, size_t n, uint32_t* __restrict__ partial) {
+  ScArgs a;
+#pragma unroll
+  for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
+  const uint32_t* z = a.t[0];
+  Fr acc = fe_zero<FrP>();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc = fe_add(acc, fe_mul(fe_load<FrP>(z + 8 * i), fe_load<FrP>(chi + 8 * i)));
+  __shared__ uint32_t sm[4][8];
+  acc = wave_sum_fr(acc);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) for (int k = 0; k < 8; k++) sm[wv][k] = acc.v[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
+    uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3);
     for (int k = 0; k < 8; k++) { o[k] = s.v[k]; o[8 + k] = 0; o[16 + k] = 0; }
   }
 }

@@ -341,3 +341,47 @@ def test_many_instances_both_launch_paths(ctx, ol, count):
     assert ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r2) == b"".join(ol.sc_eval_cubic(bound2[a], bound2[b], bound2[c]) for a, b, c in idx)
     for t in dev:
         t.free()
+
+
+@pytest.mark.parametrize("ell,count", [(1, 1), (6, 5), (11, 30)])
+def test_evaluate_many_vs_oracle(ctx, ol, sbn, ell, count):
+    """the evaluations of HashLayerProof::prove at one point (sparse_mlpoly_full.rs:907-976) with one shared eq table; more than
+    24 tables go through two launches"""
+    n = 1 << ell
+    r = rand_scalars(ell, 31 + ell)
+    chi = ol.eq_evals(r)
+    tabs = [rand_scalars(n, 500 + i) for i in range(count)]
+    dev = [ctx.table_upload(x) for x in tabs]
+    got = ctx.table_evaluate_many(dev, r)
+    assert got == b"".join(ol.fr_dot(x, chi) for x in tabs)
+    assert got[:32] == ctx.table_evaluate(dev[0], r)
+    short = ctx.table_upload(rand_scalars(max(1, n // 2), 7))
+    with pytest.raises(sbn.SbnError):
+        ctx.table_evaluate_many([dev[0], short], r)
+    short.free()
+    for t in dev:
+        t.free()
+
+
+def test_async_layers_then_free_keep_results(ctx, ol, pr):
+    """sbn_hash_layer / sbn_product_layer return without waiting and sbn_table_free does not wait either: a chain that frees
+    its inputs immediately must still produce the oracle's values (buffers are recycled in stream order)"""
+    n = 1 << 12
+    val = rand_scalars(n, 1234); g, tau = rand_scalars(1, 1), rand_scalars(1, 2)
+    want = ol.hash_layer(None, val, None, 0, g, tau)
+    for _ in range(3):
+        tv = ctx.table_upload(val)
+        h = ctx.hash_layer(None, tv, None, 0, g, tau)
+        tv.free()
+        layers = [h]
+        while len(layers[-1]) > 1:
+            layers.append(ctx.product_layer(layers[-1]))
+            if len(layers) > 2:
+                layers[-3].free(); layers[-3] = None
+        w = want
+        while len(w) > 32:
+            w = ol.product_layer(w)
+        assert ctx.table_download(layers[-1]) == w
+        for t in layers:
+            if t is not None:
+                t.free()

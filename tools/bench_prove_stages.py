@@ -55,17 +55,27 @@ def run(sbn, ctx):
         def __enter__(self): ctx.sync(); self.t0 = time.perf_counter()
         def __exit__(self, *a): ctx.sync(); stages[self.name] = stages.get(self.name, 0.0) + 1e3 * (time.perf_counter() - self.t0)
 
+    import ctypes as C
+    from spartan_bn254_amd import binding as B
+    L_ = B.lib()
+
     def cubic_batched(As, Bs, Cs):
-        """prove_cubic_batched's device work (sumcheck.rs:165-330) to the last round; returns the number of rounds"""
+        """prove_cubic_batched's device work (sumcheck.rs:165-330) to the last round; returns the number of rounds.
+        The handle arrays are built once per sumcheck, as a compiled caller would hold them."""
         tabs = list({id(t): t for t in As + Bs + Cs}.values())
         n = len(As[0]); rounds = 0
         if n < 2:
             return 0
-        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+        k = len(As)
+        a = (C.c_void_p * k)(*[t.h for t in As]); b = (C.c_void_p * k)(*[t.h for t in Bs]); c_ = (C.c_void_p * k)(*[t.h for t in Cs])
+        out = (C.c_uint8 * (96 * k))()
+        if L_.sbn_sc_eval_cubic_batched(ctx.h, a, b, c_, C.c_size_t(k), out):
+            raise RuntimeError("sbn_sc_eval_cubic_batched")
         while n >= 2:
-            r = challenge(ev); rounds += 1
+            r = challenge(bytes(out)); rounds += 1
             if n >= 4:
-                ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+                if L_.sbn_sc_bind_eval_cubic_batched(ctx.h, a, b, c_, C.c_size_t(k), (C.c_uint8 * 32).from_buffer_copy(r), out):
+                    raise RuntimeError("sbn_sc_bind_eval_cubic_batched")
             else:
                 ctx.bind_top_many(tabs, r)
             n //= 2
@@ -193,9 +203,9 @@ def run(sbn, ctx):
 
     # ------------------------------------------------------------------ hash-layer proof: evaluations + the three openings (sparse_mlpoly_full.rs:907-1010)
     big = [rand_table(nops) for _ in range(3)]
-    with timed("network proof: 23 DensePolynomial::evaluate (18 x 2^%d, 5 x 2^%d)" % (LOG_OPS, LOG_MEM)):
-        for i in range(18): ctx.table_evaluate(big[i % 3], scal(LOG_OPS))
-        for i in range(5): ctx.table_evaluate(mem_rx, scal(LOG_MEM))
+    with timed("network proof: 23 DensePolynomial::evaluate (21 at rand_ops over 2^%d, 2 at rand_mem over 2^%d)" % (LOG_OPS, LOG_MEM)):
+        ctx.table_evaluate_many([big[i % 3] for i in range(21)], scal(LOG_OPS))       # 6 derefs + 15 addr / val / read_ts polynomials (sparse_mlpoly_full.rs:907-942)
+        ctx.table_evaluate_many([mem_rx, mem_ry], scal(LOG_MEM))                       # the two audit_ts polynomials (:973-976)
     for t in big: t.free()
     opening("network proof: derefs opening", comb, dl, dr, b"gens_r1cs_eval")
     comb.free()
