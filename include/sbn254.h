@@ -190,6 +190,8 @@ int sbn_bullet_fold(sbn_ctx* ctx, sbn_bullet* st, const uint8_t u[32], const uin
 int sbn_bullet_finish(sbn_ctx* ctx, sbn_bullet* st, uint8_t a_hat[32], uint8_t b_hat[32], uint8_t g_hat_xy[64], int* g_hat_is_inf);
 
 /* ---- network construction pieces ----
+ * sbn_hash_layer and sbn_product_layer only enqueue work (their outputs are consumed by later calls on the same context, which
+ * are ordered behind them); every call that returns data to the host waits for it. ----
  * Layers::build_hash_layer (sparse_mlpoly_full.rs:745-796): out[j] = (ts[j] + ts_add) * r_hash^2 + val[j] * r_hash + addr[j] - r_multiset
  * addr_dev / ts_dev: DEVICE arrays of n uint32 (NULL addr = the cell index j, as for poly_init/audit_hashed; NULL ts = zeros);
  * ts_add = 1 gives the write set (read_ts + 1).  val: table of n entries (eval_table or a derefs poly). */
