@@ -228,6 +228,35 @@ def test_two_contexts_concurrently(sbn, ol, pr):
     b.free(); c1.close(); c2.close()
 
 
+def test_one_context_from_many_host_threads(ctx, ol, pr):
+    """B1 swapped alone is entered from Rayon workers (hyrax.rs:259-261 -> commitments.rs:152 -> group.rs:171): many host threads,
+    ONE context.  Calls serialise on the context's mutex; every thread must get its own result back."""
+    import threading
+    n = 3000
+    pts, _ = ol.gens_new(n, b"threads")
+    b = ctx.bases_upload(pts[:64 * n], pts[64 * n:])
+    ks = [rand_scalars(n, 700 + i) for i in range(16)]
+    want = [ol.msm_pippenger(k, pts[:64 * n], threads=4) for k in ks]
+    got = [None] * 16
+    tabs = [ctx.table_upload(rand_scalars(256, 800 + i)) for i in range(16)]
+    dots = [None] * 16
+
+    def work(i):
+        got[i] = ctx.msm_bases(b, ks[i])[0] if i % 2 else ctx.msm(ks[i], pts[:64 * n])[0]
+        dots[i] = ctx.table_dot(tabs[i], tabs[(i + 1) % 16])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(16)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == want
+    hs = [rand_scalars(256, 800 + i) for i in range(16)]
+    assert dots == [ol.fr_dot(hs[i], hs[(i + 1) % 16]) for i in range(16)]
+    for t in tabs:
+        t.free()
+    b.free()
+
+
 def test_shared_generators_first_commit_from_two_threads(sbn, ol):
     """two contexts commit against ONE freshly created generator set at the same time: the lazily built window table of the
     set must be built once and seen by both"""
