@@ -385,3 +385,44 @@ def test_async_layers_then_free_keep_results(ctx, ol, pr):
         for t in layers:
             if t is not None:
                 t.free()
+
+
+def test_residue_sharded_sumcheck_two_contexts(sbn, ol, pr):
+    """SURVEY 8e, sumcheck rows: tables sharded by index residue over 2 'ranks' (two contexts on this GPU, the exchange done in
+    process: sharding.fr_sum is what follows the all-gather).  Every round's sums and the final claims must equal the unsharded
+    device run and the oracle."""
+    from spartan_bn254_amd import sharding
+    n, world = 1 << 10, 2
+    full = [rand_scalars(n, 300 + i) for i in range(5)]                        # A1, B1, A2, B2, C (C shared: "par" instances)
+    ctxs = [sbn.Context(0) for _ in range(world)]
+    ref = sbn.Context(0)
+    try:
+        loc = [[cx.table_upload(sharding.shard_table_residue(t, g, world)) for t in full] for g, cx in enumerate(ctxs)]
+        whole = [ref.table_upload(t) for t in full]
+        inst = lambda T: ([T[0], T[2]], [T[1], T[3]], [T[4], T[4]])
+        chal = lambda ev: pr.scalar_to_bytes(int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % pr.R)
+        ev = sharding.fr_sum([cx.sc_eval_cubic_batched(*inst(T)) for cx, T in zip(ctxs, loc)])
+        want = ref.sc_eval_cubic_batched(*inst(whole))
+        host = list(full)
+        while True:
+            assert ev == want == ol.sc_eval_cubic(host[0], host[1], host[4]) + ol.sc_eval_cubic(host[2], host[3], host[4])
+            r = chal(ev)
+            host = [ol.bind_top(t, r) for t in host]
+            m = len(loc[0][0])
+            if m >= 4:
+                ev = sharding.fr_sum([cx.sc_bind_eval_cubic_batched(*inst(T), r) for cx, T in zip(ctxs, loc)])
+                want = ref.sc_bind_eval_cubic_batched(*inst(whole), r)
+            else:                                                            # local tables go from 2 entries to 1
+                for cx, T in zip(ctxs, loc):
+                    cx.bind_top_many(T, r)
+                ref.bind_top_many(whole, r)
+                break
+        # the residual world-entry tables: entry g comes from rank g
+        rest = [b"".join(ctxs[g].table_read0(loc[g][t]) for g in range(world)) for t in range(5)]
+        assert rest == host == [ref.table_download(t) for t in whole]
+        for T in loc + [whole]:
+            for t in T:
+                t.free()
+    finally:
+        for cx in ctxs + [ref]:
+            cx.close()
