@@ -59,9 +59,6 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
 // block (row, s) sums the columns col = s*256 + tid, + 256 S, ... and stores its accumulator to partial[(row*S + s)*256 + tid].
 // The kernel is nothing but the accumulate loop (the tree sum lives in k_comb_fold: keeping it out holds this kernel at the
 // register budget of the bucket accumulate kernel, 3 waves per SIMD instead of 2).
-// BLOCKSUM (few rows, latency-bound: occupancy is irrelevant): the block also tree-sums its 256 accumulators and stores ONE point
-// to partial[row*S + s], which leaves k_comb_fold a handful of points per row instead of thousands.
-template <bool BLOCKSUM>
 __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ skip, uint32_t* __restrict__ partial) {
   const size_t row = blockIdx.x; const unsigned S = gridDim.y;
   XYZZ acc = xyzz_inf();
@@ -81,7 +78,28 @@ __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ 
     }
     if (have) xyzz_madd(acc, p_prev, neg_prev);
   }
-  if (!BLOCKSUM) { xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc); return; }
+  xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc);
+}
+// Few rows (bullet rounds, single commits): the (window, column) pairs of a row are dealt out one by one over S*256 lanes, so
+// a lane's chain is ncol*W / (256 S) mixed additions however few columns there are, and the block sums its accumulators.
+__global__ void __launch_bounds__(256) k_comb_rows_flat(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ skip, uint32_t* __restrict__ partial) {
+  const size_t row = blockIdx.x; const unsigned S = gridDim.y;
+  XYZZ acc = xyzz_inf();
+  if (!(skip && skip[row] == 2)) {
+    const uint32_t ncol = (uint32_t)a.n, total = ncol * (uint32_t)s.W;
+    Affine p_prev; bool neg_prev = false, have = false;
+    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += S * blockDim.x) {
+      const uint32_t w = idx / ncol, col = idx - w * ncol;
+      const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      const int d = window_digit_indep(k, (int)w, s.c);
+      if (d == 0) continue;
+      const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
+      const Affine p = aff_load(table + 16 * ti);
+      if (have) xyzz_madd(acc, p_prev, neg_prev);
+      p_prev = p; neg_prev = d < 0; have = true;
+    }
+    if (have) xyzz_madd(acc, p_prev, neg_prev);
+  }
   __shared__ uint32_t sm[4][32];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   acc = wave_sum(acc, lane);

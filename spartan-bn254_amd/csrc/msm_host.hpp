@@ -276,18 +276,19 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     const MsmShape s = make_shape(b->comb_c);
     DigitArgs da; memset(&da, 0, sizeof da);
     da.scalars = dZ; da.blinds = dBl; da.n = ncol; da.R = R; da.L = L; da.tstride = npts;
-    unsigned S = 1; while ((size_t)L * S < 2048 && S < 16 && (size_t)S * 256 < ncol) S <<= 1;
+    // few rows: spread a row over S blocks so that a lane's chain is ~4 mixed additions (latency-bound regime)
+    unsigned S = 1; while ((size_t)L * S < 2048 && S < 64 && (size_t)S * 1024 < ncol * (size_t)s.W) S <<= 1;
     if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = (unsigned)v; }
     int rc;
     if ((rc = ensure(c, c->wsum, L * 128))) return rc;
-    if ((rc = ensure(c, c->comb_partial, L * S * 256 * 128))) return rc;
-    if (L > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: too many rows");
+    if ((rc = ensure(c, c->comb_partial, S > 1 ? L * S * 128 : L * 256 * 128))) return rc;
+    if (L > 0x7fffffffull || ncol * (size_t)s.W > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: too many rows / columns");
     c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(L * ncol * (size_t)s.W); c->last_job[3] = 0;
-    if (S > 1) {      // few rows: latency-bound, sum inside the block
-      LAUNCH(c, "k_comb_rows", k_comb_rows<true>, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
+    if (S > 1) {
+      LAUNCH(c, "k_comb_rows", k_comb_rows_flat, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
       LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p);
     } else {
-      LAUNCH(c, "k_comb_rows", k_comb_rows<false>, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
+      LAUNCH(c, "k_comb_rows", k_comb_rows, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
       LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, 256u, (uint32_t*)c->wsum.p);
     }
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));

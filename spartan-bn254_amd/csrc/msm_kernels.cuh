@@ -40,6 +40,21 @@ __device__ __forceinline__ int window_digit(const uint32_t* __restrict__ k /* 8 
   return (int)d;
 }
 
+// The same recoding without the carry chain: the carry INTO window w is bit (c*w - 1) of k (the lower windows represent
+// k mod 2^(cw) recentred into [-2^(cw-1), 2^(cw-1)), which borrows exactly when that bit is set), so every window can be
+// taken on its own.  Digits land in [-2^(c-1), 2^(c-1)] — the sequential rule's -2^(c-1)-with-carry corner comes out as
+// +2^(c-1) without one; both are the same number.  Used where the windows of one scalar are spread over lanes.
+__device__ __forceinline__ int window_digit_indep(const uint32_t* __restrict__ k, int w, int c) {
+  const int bit = w * c, limb = bit >> 5, sh = bit & 31;
+  uint64_t x = 0;
+  if (limb < 8) x = k[limb];
+  if (limb + 1 < 8) x |= (uint64_t)k[limb + 1] << 32;
+  const uint32_t raw = (uint32_t)(x >> sh) & ((1u << c) - 1u);
+  const uint32_t carry = bit ? (k[(bit - 1) >> 5] >> ((bit - 1) & 31)) & 1u : 0u;
+  const int d = (int)(raw + carry);
+  return (raw >> (c - 1)) ? d - (1 << c) : d;
+}
+
 // Montgomery-form scalars -> canonical integers (only when the caller passes ark-ff's in-memory limbs)
 __global__ void __launch_bounds__(256) k_scalars_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
