@@ -155,3 +155,18 @@ def test_bullet_full_size_verifier_relation(ctx, ol, pr):
     ah, bh = pr.scalar_from_bytes(got["a_hat"]), pr.scalar_from_bytes(got["b_hat"])
     rhs = ol.g1_add(ol.g1_add(ol.g1_mul(got["g_hat"], got["a_hat"]), ol.g1_mul(Q_xy, pr.scalar_to_bytes(ah * bh % R))), ol.g1_mul(H_xy, got["blind_hat"]))
     assert lhs == rhs
+
+
+def test_bullet_fuzz_sizes(ctx, ol, pr):
+    """every power of two from 2 to 256, random data, with and without Q / H / blinds"""
+    for lg in range(1, 9):
+        n = 1 << lg
+        pts, _ = ol.gens_new(n, b"fz%d" % lg)
+        G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+        Q_xy = pr.point_to_xy(pr.mul((1, 2), 1000 + lg))
+        a, b = rand_scalars(n, 3000 + lg), rand_scalars(n, 3100 + lg)
+        blind = rand_scalars(1, 3200 + lg); blinds_vec = rand_scalars(2 * lg, 3300 + lg); us = rand_scalars(lg, 3400 + lg)
+        want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
+        got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+        for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
+            assert got[k] == want[k], (n, k)

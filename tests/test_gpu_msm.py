@@ -542,3 +542,41 @@ def test_precompute_budget_errors(ctx, ol, sbn):
         assert ctx.bases_precompute(b, 1 << 20) >= 7  # idempotent
     finally:
         b.free()
+
+
+def test_fuzz_lookup_table_commits(ctx, ol, pr):
+    """random shapes / window sizes / row patterns through sbn_bases_precompute + commit: R not a power of two, 1..70 rows (every
+    blocks-per-row setting), blinds on and off, zero / constant / sparse rows, duplicate and infinite generators"""
+    import random
+    rng = random.Random(20260)
+    for case in range(14):
+        R = rng.choice([1, 2, 3, 17, 64, 100, 255, 300])
+        L = rng.choice([1, 2, 3, 8, 31, 70])
+        gx = bytearray(ol.g1_mul_gen_batch(rand_scalars(R + 1, 9000 + case)))
+        if R >= 3 and case % 3 == 0:
+            gx[64:128] = gx[0:64]                          # duplicate generator
+            gx[128:192] = bytes(64)                        # generator at infinity
+        gx = bytes(gx)
+        Z = bytearray(rand_scalars(L * R, 9100 + case))
+        for i in range(L):
+            kind = rng.randrange(5)
+            if kind == 0:
+                Z[32 * R * i:32 * R * (i + 1)] = bytes(32 * R)
+            elif kind == 1:
+                Z[32 * R * i:32 * R * (i + 1)] = Z[32 * R * i:32 * R * i + 32] * R
+            elif kind == 2:
+                for j in range(R):
+                    if rng.random() < 0.8:
+                        Z[32 * (R * i + j):32 * (R * i + j + 1)] = bytes(32)
+        Z = bytes(Z); bl = rand_scalars(L, 9200 + case)
+        b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+        try:
+            cw = ctx.bases_precompute(b, rng.choice([64, 128, 512]) << 20)
+            assert 7 <= cw <= 16
+            use_bl = case % 2 == 0
+            got, infs = ctx.commit_rows(b, Z, bl if use_bl else None, L, R)
+            want = ol.commit_rows(Z, bl if use_bl else None, L, R, gx[:64 * R], gx[64 * R:], 8)
+            assert got == want, (case, R, L, cw, use_bl)
+            assert all((infs[i] == 1) == (want[64 * i:64 * i + 64] == bytes(64)) for i in range(L))
+        finally:
+            b.free()
