@@ -542,6 +542,23 @@ def test_precompute_budget_errors(ctx, ol, sbn):
         assert ctx.bases_precompute(b, 1 << 20) >= 7  # idempotent
     finally:
         b.free()
+    # a budget the device cannot honour: the allocation fails, the call reports it, and the handle keeps working (bucket method)
+    n = 1 << 16
+    big = ctx.bases_synthetic(n, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    try:
+        with pytest.raises(sbn.SbnError):
+            ctx.bases_precompute(big, 1 << 42)        # c = 16 would need 2.2 TB
+        k = rand_scalars(n, 77)
+        dl = _arith_dlogs(pr_mod(), 0, n)
+        out, _ = ctx.commit_rows(big, k, None, 1, n)
+        assert out == ol.g1_mul(pr_mod().point_to_xy(pr_mod().G), ol.fr_dot(k, dl))
+    finally:
+        big.free()
+
+
+def pr_mod():
+    import pyref
+    return pyref
 
 
 def test_fuzz_lookup_table_commits(ctx, ol, pr):
