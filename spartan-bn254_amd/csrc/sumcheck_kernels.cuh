@@ -247,6 +247,43 @@ __global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ i
     fe_store<FrP>(out + 8 * (2 * k), fe_sub(s, hi));
   }
 }
+// two levels in one pass (r_j then r_{j+1}): in[k] -> out[4k .. 4k+3]; saves the intermediate table's write and re-read
+__global__ void __launch_bounds__(256) k_eq_level2(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, const uint32_t* __restrict__ rj_mont) {
+  const Fr r0 = fe_load<FrP>(rj_mont), r1 = fe_load<FrP>(rj_mont + 8);
+  for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < size_in; k += (size_t)gridDim.x * blockDim.x) {
+    const Fr s = fe_load<FrP>(in + 8 * k);
+    const Fr h = fe_mul(s, r0), l = fe_sub(s, h);
+    const Fr hh = fe_mul(h, r1), lh = fe_mul(l, r1);
+    fe_store<FrP>(out + 8 * (4 * k), fe_sub(l, lh));
+    fe_store<FrP>(out + 8 * (4 * k + 1), lh);
+    fe_store<FrP>(out + 8 * (4 * k + 2), fe_sub(h, hh));
+    fe_store<FrP>(out + 8 * (4 * k + 3), hh);
+  }
+}
+// the challenge vector as a kernel argument (no staging copy, no host wait): canonical -> Montgomery into r_mont[0..ell)
+constexpr int EQ_MAX_VARS = 40;
+struct EqPoint { uint32_t v[EQ_MAX_VARS][8]; };
+__global__ void __launch_bounds__(64) k_eq_prepare(EqPoint r, int ell, uint32_t* __restrict__ r_mont) {
+  const int j = threadIdx.x;
+  if (j >= ell) return;
+  Fr x;
+#pragma unroll 1
+  for (int q = 0; q < EQ_MAX_VARS; q++) if (q == j) { for (int k = 0; k < 8; k++) x.v[k] = r.v[q][k]; }
+  fe_store<FrP>(r_mont + 8 * j, fe_to_mont(x));
+}
+// the first m levels at once: out[i] = prod_j (bit_{m-1-j}(i) ? r_j : 1 - r_j), i < 2^m — the same field element the level-by-level
+// recurrence s -> (s - s r, s r) of hyrax.rs:360-366 produces (variable 0 is the most significant index bit)
+__global__ void __launch_bounds__(256) k_eq_direct(const uint32_t* __restrict__ r_mont, int m, uint32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ((size_t)1 << m)) return;
+  const Fr one = fe_one<FrP>();
+  Fr acc = one;
+  for (int j = 0; j < m; j++) {
+    const Fr r = fe_load<FrP>(r_mont + 8 * j);
+    acc = fe_mul(acc, ((i >> (m - 1 - j)) & 1) ? r : fe_sub(one, r));
+  }
+  fe_store<FrP>(out + 8 * i, acc);
+}
 // hash layer: out[j] = (ts[j]+ts_add)*g^2 + val[j]*g + addr[j] - tau.  g2rr = g^2 * R (a "doubly Montgomery" value), so one
 // Montgomery product with the plain small integer ts gives mont(ts*g^2); rr = R^2 turns the plain addr into mont(addr).
 __global__ void __launch_bounds__(256) k_hash_layer(const uint32_t* __restrict__ addr, const uint32_t* __restrict__ val, const uint32_t* __restrict__ ts, uint32_t ts_add,

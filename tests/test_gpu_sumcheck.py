@@ -128,7 +128,7 @@ def test_full_prove_cubic_loop_fused(ctx, ol, pr):
         t.free()
 
 
-@pytest.mark.parametrize("ell", [0, 1, 2, 7, 16])
+@pytest.mark.parametrize("ell", [0, 1, 2, 7, 12, 13, 15, 16, 21])      # 12 levels direct, then pairs of levels (+ one single)
 def test_eq_evals(ctx, ol, ell):
     r = rand_scalars(max(ell, 1), 3)[:32 * ell]
     t = ctx.eq_evals(r)
