@@ -59,10 +59,13 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
 // block (row, s) sums the columns col = s*256 + tid, + 256 S, ... and stores its accumulator to partial[(row*S + s)*256 + tid].
 // The kernel is nothing but the accumulate loop (the tree sum lives in k_comb_fold: keeping it out holds this kernel at the
 // register budget of the bucket accumulate kernel, 3 waves per SIMD instead of 2).
-__global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ skip, uint32_t* __restrict__ partial) {
+// Rows flagged constant or zero (flags[row] != 0) are left to k_comb_rows_const: their merged form has at most two non-zero
+// scalars, and walking all columns just to find zero digits is a chain of exposed load latencies.
+__global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ flags, uint32_t* __restrict__ partial) {
   const size_t row = blockIdx.x; const unsigned S = gridDim.y;
+  if (flags && flags[row] != 0) return;
   XYZZ acc = xyzz_inf();
-  if (!(skip && skip[row] == 2)) {
+  {
     Affine p_prev; bool neg_prev = false, have = false;
     for (size_t col = (size_t)blockIdx.y * blockDim.x + threadIdx.x; col < a.n; col += (size_t)S * blockDim.x) {
       const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
@@ -79,6 +82,27 @@ __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ 
     if (have) xyzz_madd(acc, p_prev, neg_prev);
   }
   xyzz_store(partial + 32 * ((row * S + blockIdx.y) * blockDim.x + threadIdx.x), acc);
+}
+// Constant / zero rows of a merged matrix (k_merge_small): only column col_a (the sum-of-all-bases column, carrying the row's value)
+// and col_b (the column h merged into, carrying the blind; ~0 = none) can be non-zero.  One wave per row, a lane per (column, window).
+__global__ void __launch_bounds__(64) k_comb_rows_const(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ flags, int skip_zero,
+                                                        size_t col_a, size_t col_b, uint32_t* __restrict__ sparse) {
+  const size_t row = blockIdx.x; const int lane = threadIdx.x;
+  if (flags[row] == 0) return;
+  XYZZ acc = xyzz_inf();
+  if (!(skip_zero && flags[row] == 2)) {
+    const int n2 = (col_b == ~(size_t)0) ? s.W : 2 * s.W;
+    for (int idx = lane; idx < n2; idx += 64) {
+      const size_t col = idx < s.W ? col_a : col_b; const int w = idx < s.W ? idx : idx - s.W;
+      const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      const int d = window_digit_indep(k, w, s.c);
+      if (d == 0) continue;
+      const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
+      xyzz_madd(acc, aff_load(table + 16 * ti), d < 0);
+    }
+  }
+  acc = wave_sum(acc, lane);
+  if (lane == 0) xyzz_store(sparse + 32 * row, acc);
 }
 // Few rows (bullet rounds, single commits): the (window, column) pairs of a row are dealt out one by one over S*256 lanes, so
 // a lane's chain is ncol*W / (256 S) mixed additions however few columns there are, and the block sums its accumulators.
@@ -113,9 +137,11 @@ __global__ void __launch_bounds__(256) k_comb_rows_flat(const uint32_t* __restri
 }
 // per row: `per_row` lane accumulators -> out[row].  One block per row: strided partial sums, wave tree, and — when the block has
 // four waves (many accumulators per row, i.e. few rows) — an LDS step across them.  Many rows use one wave per row.
-__global__ void __launch_bounds__(256) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out) {
+// Rows with flags[row] != 0 take the point k_comb_rows_const left in sparse[row].
+__global__ void __launch_bounds__(256) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sparse) {
   const size_t row = blockIdx.x; const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   __shared__ uint32_t sm[4][32];
+  if (flags && flags[row] != 0) { if (threadIdx.x == 0) xyzz_store(out + 32 * row, xyzz_load(sparse + 32 * row)); return; }
   XYZZ v = xyzz_inf();
   for (unsigned i = threadIdx.x; i < per_row; i += blockDim.x) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
   v = wave_sum(v, lane);

@@ -251,8 +251,15 @@ static int bases_build_comb(sbn_ctx* c, sbn_bases* b, size_t max_bytes) {
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
 // launches only (no host synchronisation): row commitments as canonical affine bytes + infinity flags in DEVICE buffers
 // (d_xy == nullptr: stop before the conversion and leave the L sums as XYZZ in c->wsum)
-static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const uint8_t* skip_rows = nullptr) {
+// A merged matrix (the recursive call of the duplicate-bases path) comes with per-row flags: 0 ordinary, 1 constant, 2 all-zero.
+struct RowInfo {
+  const uint8_t* flags = nullptr;   // null: no information
+  bool skip_zero = false;           // no blinds: an all-zero row is the identity and needs no work at all
+  size_t col_value = ~(size_t)0, col_blind = ~(size_t)0;   // the only columns a flagged row can be non-zero in
+};
+static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const RowInfo& ri = RowInfo()) {
   if (L == 0) return SBN_OK;
+  const uint8_t* skip_rows = ri.skip_zero ? ri.flags : nullptr;
   if (b->uniq) {
     // merge the scalars of equal bases, then commit over the unique bases (no blind column: h is merged like any base)
     const size_t U = b->U; int rc;
@@ -263,7 +270,9 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
     if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
-    return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf, dBl ? nullptr : rowflags);   // with blinds a zero row still commits to blind*h
+    RowInfo info; info.flags = rowflags; info.skip_zero = dBl == nullptr;      // with blinds a zero row still commits to blind*h
+    info.col_value = U; info.col_blind = (dBl && b->hcol <= U) ? (size_t)b->hcol : ~(size_t)0;
+    return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf, info);
   }
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) {
@@ -281,15 +290,19 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = (unsigned)v; }
     int rc;
     if ((rc = ensure(c, c->wsum, L * 128))) return rc;
-    if ((rc = ensure(c, c->comb_partial, S > 1 ? L * S * 128 : L * 256 * 128))) return rc;
+    if ((rc = ensure(c, c->comb_partial, S > 1 ? L * S * 128 : L * 257 * 128))) return rc;
     if (L > 0x7fffffffull || ncol * (size_t)s.W > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: too many rows / columns");
     c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(L * ncol * (size_t)s.W); c->last_job[3] = 0;
     if (S > 1) {
       LAUNCH(c, "k_comb_rows", k_comb_rows_flat, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
-      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p);
+      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p, (const uint8_t*)nullptr, (const uint32_t*)nullptr);
     } else {
-      LAUNCH(c, "k_comb_rows", k_comb_rows, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
-      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, 256u, (uint32_t*)c->wsum.p);
+      // ordinary rows: one block each; flagged (constant / zero) rows: one wave each over their one or two live columns
+      const uint8_t* fl = (ri.flags && ri.col_value != ~(size_t)0) ? ri.flags : nullptr;
+      uint32_t* sparse = (uint32_t*)c->comb_partial.p + (size_t)32 * L * 256;
+      LAUNCH(c, "k_comb_rows", k_comb_rows, dim3((unsigned)L, 1), 256, (const uint32_t*)b->d_comb, da, s, fl, (uint32_t*)c->comb_partial.p);
+      if (fl) LAUNCH(c, "k_comb_rows_const", k_comb_rows_const, (unsigned)L, 64, (const uint32_t*)b->d_comb, da, s, fl, ri.skip_zero ? 1 : 0, ri.col_value, ri.col_blind, sparse);
+      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, 256u, (uint32_t*)c->wsum.p, fl, (const uint32_t*)sparse);
     }
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));
     if (d_xy) LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
