@@ -228,6 +228,20 @@ __global__ void __launch_bounds__(256) k_bind_top(uint32_t* const* __restrict__ 
   }
 }
 
+// the same with the table pointers and the challenge as kernel arguments (up to BIND_PACK_MAX tables): nothing to stage, nothing to wait for
+constexpr int BIND_PACK_MAX = 64;
+struct BindPack { uint32_t* t[BIND_PACK_MAX]; };
+__global__ void __launch_bounds__(256) k_bind_top_packed(BindPack pack, size_t half, ScScalar rc) {
+  uint32_t* Z = nullptr;
+#pragma unroll
+  for (int i = 0; i < BIND_PACK_MAX; i++) if (i == (int)blockIdx.y) Z = pack.t[i];
+  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rc.v[k];
+  r = fe_to_mont(r);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
+    fe_store<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
+  }
+}
 __global__ void __launch_bounds__(256) k_fr_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     fe_store<FrP>(out + 8 * i, fe_to_mont(fe_load<FrP>(in + 8 * i)));

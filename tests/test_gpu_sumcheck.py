@@ -426,3 +426,19 @@ def test_residue_sharded_sumcheck_two_contexts(sbn, ol, pr):
     finally:
         for cx in ctxs + [ref]:
             cx.close()
+
+
+@pytest.mark.parametrize("count", [1, 64, 70])
+def test_bind_many_both_paths(ctx, ol, count):
+    """up to 64 tables: pointers + challenge as kernel arguments (no host wait); more: staged pointer array"""
+    n = 64
+    tabs = [rand_scalars(n, 1500 + i) for i in range(count)]
+    dev = [ctx.table_upload(x) for x in tabs]
+    r = rand_scalars(1, 42)
+    ctx.bind_top_many(dev, r)
+    r2 = rand_scalars(1, 43)
+    ctx.bind_top_many(dev, r2)                     # back to back, nothing in between waits for the device
+    for t, h in zip(dev, tabs):
+        assert len(t) == n // 4 and ctx.table_download(t) == ol.bind_top(ol.bind_top(h, r), r2)
+    for t in dev:
+        t.free()
