@@ -161,5 +161,31 @@ def sumcheck_kat():
     dump("sumcheck_kat.json", out)
 
 
+def bullet_kat():
+    """BulletReductionProof::prove (nizk/bullet.rs:41-126) on the reference test's setup (n = 8, label "test-gens", Q = G,
+    bullet.rs:222-238) and on n = 4 with repeated generators, challenges fixed."""
+    rnd = random.Random(8128)
+    out = {"cases": []}
+    for n, label in ((8, b"test-gens"), (4, b"gens_r1cs_eval")):
+        lg = n.bit_length() - 1
+        d = pr.gens_dlogs(n, label)
+        G = [pr.mul(pr.G, s) for s in d[:n]]; H = pr.mul(pr.G, d[n])
+        Q = pr.G if n == 8 else pr.mul(pr.G, 12345)
+        a = [rnd.randrange(pr.R) for _ in range(n)]; b = [rnd.randrange(pr.R) for _ in range(n)]
+        blind = rnd.randrange(pr.R)
+        bv = [(rnd.randrange(pr.R), rnd.randrange(pr.R)) for _ in range(lg)]
+        us = [rnd.randrange(1, pr.R) for _ in range(lg)]
+        o = pr.bullet_prove(G, Q, H, a, b, blind, bv, us)
+        out["cases"].append({"n": n, "label": label.decode(), "G": "".join(pt(x) for x in G), "H": pt(H), "Q": pt(Q),
+                             "a": "".join(sc(x) for x in a), "b": "".join(sc(x) for x in b), "blind": sc(blind),
+                             "blinds_vec": "".join(sc(x) + sc(y) for x, y in bv), "us": "".join(sc(x) for x in us),
+                             "L": "".join(pt(x) for x in o["L"]), "R": "".join(pt(x) for x in o["R"]), "Gamma": pt(o["Gamma"]),
+                             "a_hat": sc(o["a_hat"]), "b_hat": sc(o["b_hat"]), "g_hat": pt(o["g_hat"]), "blind_hat": sc(o["blind_hat"])})
+    dump("bullet_kat.json", out)
+
+
 if __name__ == "__main__":
-    field_kat(); g1_kat(); msm_kat(); gens_kat(); commit_kat(); sumcheck_kat()
+    if len(sys.argv) > 1 and sys.argv[1] == "bullet":
+        bullet_kat()
+    else:
+        field_kat(); g1_kat(); msm_kat(); gens_kat(); commit_kat(); sumcheck_kat(); bullet_kat()

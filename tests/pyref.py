@@ -224,3 +224,25 @@ def prng_scalars(n, seed=0x5BA27A2B4E254):
             v |= w << (64 * j)
         out.append(v % R)
     return out
+
+
+def bullet_prove(G, Q, H, a, b, blind, blinds_vec, us):
+    """nizk/bullet.rs:41-126 with the Fiat-Shamir challenges given (ints / point tuples in, dict out): the definition, with
+    per-round generator folds exactly as the reference writes them."""
+    G = list(G); a = list(a); b = list(b)
+    n = len(G)
+    Gamma = add(add(msm(a, G), mul(Q, sum(x * y for x, y in zip(a, b)) % R)), mul(H, blind))
+    Ls, Rs = [], []
+    bg = blind
+    for (bl, br), u in zip(blinds_vec, us):
+        n //= 2
+        ui = pow(u, R - 2, R)
+        cL = sum(x * y for x, y in zip(a[:n], b[n:])) % R
+        cR = sum(x * y for x, y in zip(a[n:], b[:n])) % R
+        Ls.append(add(add(msm(a[:n], G[n:]), mul(Q, cL)), mul(H, bl)))
+        Rs.append(add(add(msm(a[n:], G[:n]), mul(Q, cR)), mul(H, br)))
+        G = [add(mul(G[i], ui), mul(G[i + n], u)) for i in range(n)]
+        a = [(u * a[i] + ui * a[i + n]) % R for i in range(n)]
+        b = [(ui * b[i] + u * b[i + n]) % R for i in range(n)]
+        bg = (u * u * bl + bg + ui * ui * br) % R
+    return {"L": Ls, "R": Rs, "Gamma": Gamma, "a_hat": a[0], "b_hat": b[0], "g_hat": G[0], "blind_hat": bg}

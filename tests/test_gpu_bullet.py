@@ -170,3 +170,13 @@ def test_bullet_fuzz_sizes(ctx, ol, pr):
         got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
         for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
             assert got[k] == want[k], (n, k)
+
+
+def test_bullet_golden(ctx, pr):
+    """the committed fixture (pure-Python model, tests/golden/make_golden.py) through the C ABI"""
+    from conftest import golden
+    H = bytes.fromhex
+    for case in golden("bullet_kat.json")["cases"]:
+        got = _run_device(ctx, pr, H(case["G"]), H(case["H"]), H(case["Q"]), H(case["a"]), H(case["b"]), H(case["blind"]), H(case["blinds_vec"]), H(case["us"]))
+        for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
+            assert got[k] == H(case[k]), (case["n"], k)

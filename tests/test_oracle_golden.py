@@ -206,3 +206,13 @@ def test_oracle_bullet_reduction_verifier_relations(ol, pr):
     ah, bh, rh = (pr.scalar_from_bytes(o[k]) for k in ("a_hat", "b_hat", "blind_hat"))
     rhs = pr.add(pr.add(pr.mul(pr.point_from_xy(o["g_hat"]), ah), pr.mul(Q, ah * bh % R)), pr.mul(H, rh))
     assert lhs == rhs
+
+
+def test_oracle_bullet_vs_python_model(ol):
+    """tests/golden/bullet_kat.json comes from tests/pyref.py (per-round generator folds written as the reference writes them,
+    Python integers): the C oracle must reproduce every output."""
+    H = bytes.fromhex
+    for case in golden("bullet_kat.json")["cases"]:
+        o = ol.bullet_prove(H(case["G"]), H(case["Q"]), H(case["H"]), H(case["a"]), H(case["b"]), H(case["blind"]), H(case["blinds_vec"]), H(case["us"]))
+        for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
+            assert o[k] == H(case[k]), (case["n"], k)
