@@ -130,4 +130,14 @@ __device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& p, int delta) {
   return r;
 }
 
+__device__ __forceinline__ XYZZ xyzz_shfl_xor(const XYZZ& p, int mask) {
+  XYZZ r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.X.v[i] = __shfl_xor(p.X.v[i], mask, 64); r.Y.v[i] = __shfl_xor(p.Y.v[i], mask, 64);
+    r.ZZ.v[i] = __shfl_xor(p.ZZ.v[i], mask, 64); r.ZZZ.v[i] = __shfl_xor(p.ZZZ.v[i], mask, 64);
+  }
+  return r;
+}
+
 }  // namespace sbn

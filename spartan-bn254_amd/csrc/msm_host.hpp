@@ -70,13 +70,16 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   // enough segments to fill the chip when a problem has few, heavily loaded buckets (one row, many columns)
   if (NB < 262144) { const size_t total = J.P * estride; uint32_t cap = 32; while ((size_t)cap * 262144 < total && cap < ACC_SEG_MAX) cap <<= 1; if (SEG > cap) SEG = cap; }
   if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
+  // lanes per bucket (k_acc_first<G>): chains of ~32 mixed additions when the buckets are loaded enough to be split
+  int LPB = 1; if (J.mode == MODE_SINGLE && mean >= 48) LPB = 2;
+  if (const char* eg = getenv("SBN_ACC_G")) { int v = atoi(eg); if (v == 1 || v == 2 || v == 4) LPB = v; }
   const size_t max_extra = J.P * estride / SEG + 1;
   const size_t max_big = std::min(NB, max_extra);
   int rc;
   if ((rc = ensure(c, c->hist, NB * 4))) return rc;
   if ((rc = ensure(c, c->offs, NB * 4))) return rc;
   if ((rc = ensure(c, c->sorted, J.P * estride * 4))) return rc;
-  if ((rc = ensure(c, c->buckets, NB * 128))) return rc;
+  if ((rc = ensure(c, c->buckets, NB * 128 * (size_t)LPB))) return rc;
   if ((rc = ensure(c, c->acc_ctr, 64))) return rc;
   if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
   if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
@@ -140,12 +143,16 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
   LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
   unsigned ab = 256; if (const char* eb = getenv("SBN_ACC_BLOCK")) { int v = atoi(eb); if (v == 64 || v == 128 || v == 256) ab = (unsigned)v; }
-  LAUNCH(c, "k_acc_first", k_acc_first, (unsigned)((NB + ab - 1) / ab), ab, J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr,
-         (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p);
+  const unsigned agrid = (unsigned)((NB * (size_t)LPB + ab - 1) / ab);
+#define ACC_FIRST_ARGS J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr, (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p
+  if (LPB == 1) LAUNCH(c, "k_acc_first", k_acc_first<1>, agrid, ab, ACC_FIRST_ARGS);
+  else if (LPB == 2) LAUNCH(c, "k_acc_first", k_acc_first<2>, agrid, ab, ACC_FIRST_ARGS);
+  else LAUNCH(c, "k_acc_first", k_acc_first<4>, agrid, ab, ACC_FIRST_ARGS);
+#undef ACC_FIRST_ARGS
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
-  LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
-  LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets);
-  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks);
+  LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
+  LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
   int G = chunks, logM = 6 + logL;
   for (;;) {

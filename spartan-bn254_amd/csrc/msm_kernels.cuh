@@ -353,17 +353,28 @@ __global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restric
   if (t < nbuckets) perm[base[key] + rank] = (uint32_t)t;
 }
 
+// G lanes per bucket: each takes 1/G of the bucket's first SEG entries and stores its own partial sum (bucket t owns slots
+// t*G .. t*G+G-1); the reduction adds the G partials as it loads a bucket.  Shorter chains for the same work: the launch ramps
+// down on chains of cnt/G additions instead of cnt, and the short top window's double-length buckets stop being the critical
+// path — without touching the accumulate kernel's register budget (a fold inside this kernel costs a wave per SIMD).
+template <int G>
 __global__ void __launch_bounds__(256) k_acc_first(const uint32_t* __restrict__ points, size_t nbuckets, int nb, size_t estride, uint32_t SEG,
                                                    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ sorted,
                                                    const uint32_t* __restrict__ perm,
                                                    uint32_t* __restrict__ buckets, AccCounters* __restrict__ ctr, ExtraItem* __restrict__ extra, BigItem* __restrict__ big) {
-  const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t0 >= nbuckets) return;
-  const size_t t = perm[t0];
-  const uint32_t cnt = hist[t];
-  const uint32_t* lst = sorted + (t / nb) * estride + offs[t];
-  const XYZZ acc = acc_segment(points, lst, 0, cnt < SEG ? cnt : SEG);
-  xyzz_store(buckets + 32 * t, acc);
+  const size_t gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t0 = gl / G; const uint32_t part = (uint32_t)(gl % G);
+  const bool live = t0 < nbuckets;
+  const size_t t = live ? perm[t0] : 0;
+  const uint32_t cnt = live ? hist[t] : 0;
+  const uint32_t* lst = sorted + (t / nb) * estride + (live ? offs[t] : 0);
+  const uint32_t first = cnt < SEG ? cnt : SEG;
+  const uint32_t per = (first + G - 1) / G;
+  uint32_t from = part * per, to = from + per; if (from > first) from = first; if (to > first) to = first;
+  const XYZZ acc = acc_segment(points, lst, from, to);
+  if (!live) return;
+  xyzz_store(buckets + 32 * (t * G + part), acc);        // G partial sums per bucket, folded by k_reduce_l1 as it loads them
+  if (part) return;
   if (cnt > SEG) {
     const uint32_t k = (cnt + SEG - 1) / SEG - 1;
     const uint32_t base = atomicAdd(&ctr->extra_count, k);
@@ -413,47 +424,54 @@ __device__ __forceinline__ XYZZ xyzz_mul_pow2(XYZZ v, int k) {
 // folding the extra partials back into their bucket: a bucket with few of them is finished by one lane (64 buckets per
 // wave), a bucket with many by one whole wave (lane-strided chains, then a wave tree)
 constexpr uint32_t MERGE_LANE_MAX = 12;
-__global__ void __launch_bounds__(256) k_acc_merge_few(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets) {
+// (`G` = slots per bucket: the extras are folded into the bucket's first slot)
+__global__ void __launch_bounds__(256) k_acc_merge_few(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets, int G) {
   const uint32_t total = ctr->big_count;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const BigItem bi = big[i];
     if (bi.k > MERGE_LANE_MAX) continue;
-    XYZZ acc = xyzz_load(buckets + 32 * (size_t)bi.bucket);
+    XYZZ acc = xyzz_load(buckets + 32 * (size_t)bi.bucket * G);
     for (uint32_t j = 0; j < bi.k; j++) acc = xyzz_add(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
-    xyzz_store(buckets + 32 * (size_t)bi.bucket, acc);
+    xyzz_store(buckets + 32 * (size_t)bi.bucket * G, acc);
   }
 }
-__global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets) {
+__global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets, int G) {
   const int lane = threadIdx.x;
   const uint32_t total = ctr->big_count;
   for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
     const BigItem bi = big[i];
     if (bi.k <= MERGE_LANE_MAX) continue;
-    XYZZ acc = (lane == 0) ? xyzz_load(buckets + 32 * (size_t)bi.bucket) : xyzz_inf();
+    XYZZ acc = (lane == 0) ? xyzz_load(buckets + 32 * (size_t)bi.bucket * G) : xyzz_inf();
     for (uint32_t j = lane; j < bi.k; j += 64) acc = xyzz_add_inl(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
     acc = wave_sum(acc, lane);
-    if (lane == 0) xyzz_store(buckets + 32 * (size_t)bi.bucket, acc);
+    if (lane == 0) xyzz_store(buckets + 32 * (size_t)bi.bucket * G, acc);
   }
 }
 
 // level 1: one wave per chunk of 64*L consecutive buckets of one problem (window).
 //   S  = sum_i X_i ,  Wt = sum_i i * X_i   (i = 0-based index inside the chunk)
 // out[chunk] = {S, Wt}
-__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem) {
+// G = partial sums per bucket (k_acc_first<G>): bucket i of the chunk is the sum of slots i*G .. i*G+G-1.
+__device__ __forceinline__ XYZZ bucket_load(const uint32_t* __restrict__ p, int G) {
+  XYZZ x = xyzz_load(p);
+  for (int g = 1; g < G; g++) x = xyzz_add_inl(x, xyzz_load(p + 32 * g));
+  return x;
+}
+__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem, int G) {
   const int lane = threadIdx.x;
   const size_t chunk = blockIdx.x;
   if (skip && skip[chunk / chunks_per_problem] == 2) {   // all-zero row: nothing was accumulated
     if (lane == 0) { xyzz_store(out + 64 * chunk, xyzz_inf()); xyzz_store(out + 64 * chunk + 32, xyzz_inf()); }
     return;
   }
-  const uint32_t* base = X + 32 * ((chunk * 64 + lane) * (size_t)L);
+  const uint32_t* base = X + 32 * ((chunk * 64 + lane) * (size_t)L) * G;
   // lane-sequential running sums over its L buckets: run = sum X_i, acc = sum i*X_i (local i)
   XYZZ run = xyzz_inf(), acc = xyzz_inf();
   for (int i = L - 1; i >= 1; i--) {
-    run = xyzz_add_inl(run, xyzz_load(base + 32 * (size_t)i));
+    run = xyzz_add_inl(run, bucket_load(base + 32 * (size_t)i * G, G));
     acc = xyzz_add_inl(acc, run);
   }
-  run = xyzz_add_inl(run, xyzz_load(base));
+  run = xyzz_add_inl(run, bucket_load(base, G));
   // across lanes: index = lane*L + local  =>  Wt = sum_l acc_l + L * sum_l l * run_l
   XYZZ suf = wave_suffix_scan(run, lane);          // suf_l = sum_{l'>=l} run_l'
   XYZZ S = suf;                                    // lane 0 holds the chunk total
