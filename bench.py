@@ -301,7 +301,11 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes/launch from separate rocprofv3 --pmc passes
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(args.workload, {}).get(dominant)
+                per_kernel = json.load(open(pmc_path)).get(args.workload, {})
+                traffic = per_kernel.get(dominant)
+                if traffic is None:                     # template instances are recorded as name<args>: take the busiest one
+                    inst = [v for k, v in per_kernel.items() if k.startswith(dominant + "<")]
+                    traffic = max(inst) if inst else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
