@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Randomised soak of the C ABI against the oracle (test infrastructure, like tests/): MSMs, row commits (bucket and lookup paths),
+sumcheck rounds and bullet reductions of random shapes until the time budget is spent.  Usage: python tools/soak.py [seconds] [seed]"""
+import hashlib
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from conftest import load_pkg, rand_scalars  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+import pyref as pr  # noqa: E402
+
+sbn = load_pkg()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+ctx = sbn.Context(0)
+t_end = time.time() + budget
+counts = {"msm": 0, "commit": 0, "sumcheck": 0, "bullet": 0}
+
+
+def special(b, n):
+    """sprinkle edge scalars into a scalar blob"""
+    b = bytearray(b)
+    for _ in range(min(n, 6)):
+        i = rng.randrange(n); v = rng.choice([0, 1, pr.R - 1, pr.R - 2, 1 << 253, (1 << 128) - 1, 1 << 15, (1 << 16) - 1, (1 << 32) - 1])
+        b[32 * i:32 * i + 32] = pr.scalar_to_bytes(v % pr.R)
+    return bytes(b)
+
+
+case = 0
+while time.time() < t_end:
+    case += 1
+    kind = rng.choice(["msm", "commit", "commit", "sumcheck", "bullet"])
+    sd = rng.randrange(1 << 30)
+    if kind == "msm":
+        n = rng.choice([1, 2, 3, 31, 64, 257, 1000, 4097, 20000, 70000, 150000])
+        k = special(rand_scalars(n, sd), n)
+        pts = bytearray(ol.g1_mul_gen_batch(rand_scalars(n, sd + 1), 8))
+        if n > 3 and rng.random() < 0.5:
+            pts[64:128] = pts[0:64]; pts[128:192] = bytes(64)
+        pts = bytes(pts)
+        got = ctx.msm(k, pts)[0]
+        assert got == ol.msm_pippenger(k, pts, 8), ("msm", n, sd)
+    elif kind == "commit":
+        R = rng.choice([1, 5, 64, 100, 1024, 3000]); L = rng.choice([1, 2, 7, 33, 130])
+        label = rng.choice([b"gens_r1cs_eval", b"gens_r1cs_sat", b"x%d" % sd])
+        gx, _ = ol.gens_new(R, label, 8)
+        Z = bytearray(special(rand_scalars(L * R, sd), L * R))
+        for i in range(L):
+            m = rng.randrange(6)
+            if m == 0: Z[32 * R * i:32 * R * (i + 1)] = bytes(32 * R)
+            elif m == 1: Z[32 * R * i:32 * R * (i + 1)] = Z[32 * R * i:32 * R * i + 32] * R
+        Z = bytes(Z); bl = rand_scalars(L, sd + 2) if rng.random() < 0.5 else None
+        b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+        want = ol.commit_rows(Z, bl, L, R, gx[:64 * R], gx[64 * R:], 8)
+        assert ctx.commit_rows(b, Z, bl, L, R)[0] == want, ("commit bucket", L, R, sd)
+        if rng.random() < 0.6:
+            ctx.bases_precompute(b, rng.choice([256, 1024, 4096]) << 20)
+            assert ctx.commit_rows(b, Z, bl, L, R)[0] == want, ("commit lookup", L, R, sd)
+        b.free()
+    elif kind == "sumcheck":
+        logn = rng.choice([1, 2, 5, 9, 13]); n = 1 << logn; cnt = rng.choice([1, 3, 18, 30])
+        tabs = [rand_scalars(n, sd + i) for i in range(cnt + 2)]
+        dev = [ctx.table_upload(x) for x in tabs]
+        idx = [(i, i + 1, i + 2) for i in range(cnt)]
+        As, Bs, Cs = ([dev[t[j]] for t in idx] for j in range(3))
+        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+        host = list(tabs)
+        while True:
+            assert ev == b"".join(ol.sc_eval_cubic(host[a], host[b], host[c]) for a, b, c in idx), ("sumcheck", logn, cnt, sd)
+            r = pr.scalar_to_bytes(int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % pr.R)
+            host = [ol.bind_top(x, r) for x in host]
+            if len(dev[0]) >= 4 and rng.random() < 0.8:
+                ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+            else:
+                ctx.bind_top_many(dev, r)
+                if len(dev[0]) < 2: break
+                ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+        assert [ctx.table_read0(t) for t in dev] == host, ("sumcheck final", logn, cnt, sd)
+        for t in dev: t.free()
+    else:
+        lg = rng.randrange(1, 8); n = 1 << lg
+        pts, _ = ol.gens_new(n, rng.choice([b"gens_r1cs_eval", b"b%d" % sd]), 8)
+        G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+        Q_xy = pr.point_to_xy(pr.mul((1, 2), 1 + sd))
+        a, b = special(rand_scalars(n, sd), n), special(rand_scalars(n, sd + 1), n)
+        blind = rand_scalars(1, sd + 2); bv = rand_scalars(2 * lg, sd + 3); us = rand_scalars(lg, sd + 4)
+        want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, bv, us)
+        G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+        st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, blind)
+        assert Gamma == want["Gamma"], ("bullet gamma", n, sd)
+        for rnd in range(lg):
+            L, _, Rp, _, _, _ = ctx.bullet_cross(st, bv[64 * rnd:64 * rnd + 32], bv[64 * rnd + 32:64 * rnd + 64])
+            assert L == want["L"][64 * rnd:64 * rnd + 64] and Rp == want["R"][64 * rnd:64 * rnd + 64], ("bullet round", n, rnd, sd)
+            u = us[32 * rnd:32 * rnd + 32]
+            ctx.bullet_fold(st, u, pr.scalar_to_bytes(pow(pr.scalar_from_bytes(u), pr.R - 2, pr.R)))
+        ah, bh, gh = ctx.bullet_finish(st)
+        assert (ah, bh, gh) == (want["a_hat"], want["b_hat"], want["g_hat"]), ("bullet finish", n, sd)
+        st.free(); ta.free(); tb.free(); G.free()
+    counts[kind] += 1
+print("soak OK:", counts, "cases in %.0f s" % budget)
