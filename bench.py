@@ -87,8 +87,8 @@ def fr_dot_arith(scalars, first, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", choices=["msm", "hyrax"], default="msm")
     ap.add_argument("--log-n", type=int, default=20, help="msm: log2 of the points per GPU")
     ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows per GPU")
@@ -278,7 +278,7 @@ def main():
     # are not stretched by other streams' kernels running beside them
     serial = None
     if M > 1:
-        ns_ser = max(2, min(8, args.steps))
+        ns_ser = max(2, min(16, args.steps))
         ctx.prof_enable(True); ctx.prof_reset()
         barrier(); ts0 = time.perf_counter()
         for _ in range(ns_ser):
