@@ -199,6 +199,10 @@ int sbn_hash_layer(sbn_ctx* ctx, const void* addr_dev, const sbn_table* val, con
                    const uint8_t r_hash[32], const uint8_t r_multiset[32], sbn_table** out);
 /* ProductCircuit::compute_layer (product_tree.rs:21-37): the next layer's full vector out[i] = in[i] * in[i + len/2] */
 int sbn_product_layer(sbn_ctx* ctx, const sbn_table* in, sbn_table** out);
+/* ProductCircuit::new (product_tree.rs:39-57): every layer above `in` in one call — layers[0] = compute_layer(in) (len/2 entries),
+ * layers[k] = compute_layer(layers[k-1]), down to the single-entry layer whose value is the circuit's product (evaluate(), :59-66).
+ * cap = size of the caller's array (log2(len) layers are produced), *count <- number written.  Enqueued only, like sbn_product_layer. */
+int sbn_product_circuit(sbn_ctx* ctx, const sbn_table* in, sbn_table** layers, size_t cap, size_t* count);
 /* DensePolynomial::split(len/2) (hyrax.rs:186-192) as views: left = first half, right = second half of `t` (the A and B tables of
  * a product-circuit layer).  Views share t's memory and must be freed before t. */
 int sbn_table_halves(sbn_ctx* ctx, const sbn_table* t, sbn_table** left, sbn_table** right);

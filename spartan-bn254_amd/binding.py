@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -334,6 +334,13 @@ class Context:
 
     def product_layer(self, t):
         ht = C.c_void_p(); self._chk(lib().sbn_product_layer(self.h, t.h, C.byref(ht)), "sbn_product_layer"); return Table(self, ht)
+
+    def product_circuit(self, t):
+        """all layers above t (ProductCircuit::new): list of Tables of len/2, len/4, ..., 1 entries"""
+        cap = max(1, len(t).bit_length())
+        arr = (C.c_void_p * cap)(); cnt = C.c_size_t(0)
+        self._chk(lib().sbn_product_circuit(self.h, t.h, arr, C.c_size_t(cap), C.byref(cnt)), "sbn_product_circuit")
+        return [Table(self, C.c_void_p(arr[i])) for i in range(cnt.value)]
 
     def table_halves(self, t):
         l, r = C.c_void_p(), C.c_void_p()

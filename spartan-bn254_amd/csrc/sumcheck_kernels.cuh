@@ -321,6 +321,24 @@ __global__ void __launch_bounds__(256) k_product_layer(const uint32_t* __restric
     fe_store<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
 }
 // g (canonical) -> {mont(g), g^2 * R^2 mod r (= mont(mont(g^2))), mont(tau)}
+// the top of a product tree in one launch: from a layer of `len` <= 2048 entries down to the single product, one block, one layer
+// after the other (out[k] has len >> (k+1) entries); saves ~10 launches per circuit, which is what the small layers cost
+constexpr int PT_TAIL_MAX = 12;
+struct ProductTail { uint32_t* out[PT_TAIL_MAX]; };
+__global__ void __launch_bounds__(1024) k_product_tail(const uint32_t* __restrict__ in, size_t len, ProductTail pt) {
+  const uint32_t* src = in;
+  int k = 0;
+  for (size_t half = len / 2; half >= 1; half >>= 1, k++) {
+    uint32_t* dst = nullptr;
+#pragma unroll
+    for (int i = 0; i < PT_TAIL_MAX; i++) if (i == k) dst = pt.out[i];
+    for (size_t i = threadIdx.x; i < half; i += blockDim.x) fe_store<FrP>(dst + 8 * i, fe_mul(fe_load<FrP>(src + 8 * i), fe_load<FrP>(src + 8 * (i + half))));
+    __threadfence_block();
+    __syncthreads();
+    src = dst;
+    if (half == 1) break;
+  }
+}
 __global__ void k_hash_consts(ScScalar g_canon, ScScalar tau_canon, uint32_t* __restrict__ consts) {
   if (threadIdx.x || blockIdx.x) return;
   Fr g, t; for (int k = 0; k < 8; k++) { g.v[k] = g_canon.v[k]; t.v[k] = tau_canon.v[k]; }

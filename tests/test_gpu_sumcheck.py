@@ -442,3 +442,23 @@ def test_bind_many_both_paths(ctx, ol, count):
         assert len(t) == n // 4 and ctx.table_download(t) == ol.bind_top(ol.bind_top(h, r), r2)
     for t in dev:
         t.free()
+
+
+@pytest.mark.parametrize("logn", [1, 2, 9])
+def test_product_circuit_one_call(ctx, ol, sbn, logn):
+    """ProductCircuit::new (product_tree.rs:39-57) in one call == repeated compute_layer (oracle), down to the product itself"""
+    n = 1 << logn
+    v = rand_scalars(n, 4000 + logn)
+    t = ctx.table_upload(v)
+    layers = ctx.product_circuit(t)
+    assert [len(x) for x in layers] == [n >> (k + 1) for k in range(logn)]
+    w = v
+    for x in layers:
+        w = ol.product_layer(w)
+        assert ctx.table_download(x) == w
+    for x in layers:
+        x.free()
+    one = ctx.table_upload(rand_scalars(1, 5))
+    with pytest.raises(sbn.SbnError):
+        ctx.product_circuit(one)
+    one.free(); t.free()

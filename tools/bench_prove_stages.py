@@ -172,8 +172,8 @@ def run(sbn, ctx):
                 ops_circ.append([ctx.hash_layer(addr[k].data_ptr(), val, read_ts[k].data_ptr(), 1, g_, tau_)])   # write set
                 val.free()
         for circ in ops_circ + mem_circ:
-            while len(circ[-1]) > 2:
-                circ.append(ctx.product_layer(circ[-1]))
+            layers = ctx.product_circuit(circ[0])                      # ProductCircuit::new in one call
+            circ.extend(layers[:-1]); layers[-1].free()               # the 1-entry top layer is the product itself (needs no sumcheck)
 
     # ------------------------------------------------------------------ network proof: batched cubic sumchecks (product_tree.rs:261-340)
     def layered_proof(name, circs, extra_bottom):
