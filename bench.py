@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py — throughput of the MI355X MSM hot path (BASELINE.json metric: BN254 G1 MSM points/s).
+"""bench.py — throughput of the MI355X MSM hot path (BASELINE.json metric: BN254 G1 MSM points/s) and, in the same JSON line,
+the other workloads SURVEY 8(d) names.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload msm|hyrax] [--log-n 20]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--blocks all|none|hyrax,sweep,sumcheck]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    (python bench.py --gpus N without a launcher starts the N ranks itself, before anything touches the GPU)
 
-A step = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-  msm    (default; BASELINE configs[1]) one MSM of 2^log_n points per GPU: uniform scalars, distinct bases with known
-         discrete logs.  With N > 1 the MSM of N*2^log_n points is sharded by base-point range, each
-         rank computes its partial sum, and ONE all-gather of the 64-byte partials over RCCL + a local fold finishes it
-         (weak scaling: per-GPU work fixed).
-  hyrax  (BASELINE configs[2]) the derefs commitment shape: 4096 x 8192 scalars against the reference's 8192(+h) shared
-         generators (~66 % of them equal to G), rows 3072.. zero; with N > 1 every rank commits its own matrix (rows are
-         independent: no data-path collective).
-Before timing, the result is checked bit-for-bit against the discrete-log identity / the CPU oracle.
+Headline (`value`, `ms_per_step`, `roofline`, `cpu_baseline`; BASELINE configs[1] / SURVEY 8d config 2): one MSM of 2^log_n points
+per GPU per step — uniform full-width scalars (SplitMix64, reduced mod r), distinct bases with known discrete logs, inputs
+resident in HBM.  With N > 1 the MSM of N*2^log_n points is sharded by base-point range; each rank's 64-byte partial sum goes
+through ONE all-gather over RCCL and a local fold (weak scaling: per-GPU work fixed).
+
+Further blocks on the same line, each parity-gated before it is timed, one step in flight:
+  hyrax      config 3: the derefs commitment shape, 4096 x 8192 uniform Fr scalars (rows 3072.. zero, hyrax.rs:245) against the
+             reference's own generator set MultiCommitGens::new(8192, "gens_r1cs_eval"); fixed-base lookup table and bucket method;
+             sampled rows checked against the CPU oracle; roofline with 32.02 B / pair.  With N > 1: ONE matrix, interleaved rows
+             per rank (sharding.shard_rows), joined with gather_rows and checked.
+  msm_sweep  2^22, 2^24, 2^26 points on one GPU (checked against the discrete-log identity).  With N > 1: config 4, the FIXED
+             2^26-point MSM cut into N base-point ranges (strong scaling), folded over RCCL and checked.
+  sumcheck   config 5's dominant sumcheck: prove_cubic_batched layer 0 of the ops product circuits, 12 "par" + 6 "seq" instances
+             over 2^21-entry tables (2.7 GiB touched in round 0), 21 rounds; GB/s of algorithmic bytes against the 8 TB/s HBM peak.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,23 +34,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from __graft_entry__ import load_pkg  # noqa: E402
-
 R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
 MADD_PEAK = 1.2e10             # xyzz mixed additions/s with operands in registers, whole chip (tools/micro/ecbench.hip, measured on MI355X)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable streaming)
 S0 = 0x1234567890abcdef1234567890abcdef
 DSTEP = 0x0fedcba987654321
+SEED = 0x5BA27A2B4E254
+G_XY = bytes([1]) + bytes(31) + bytes([2]) + bytes(31)
 
 
-def splitmix_scalars(n, seed):
-    """n uniform canonical Fr scalars (32 B LE each) from SplitMix64, vectorised"""
+def splitmix_scalars(n, seed, first=0):
+    """n uniform canonical Fr scalars (32 B LE each) from SplitMix64, numpy: the host twin of
+    sbn_scalars_synthetic (tests compare the two)"""
+    import numpy as np
     with np.errstate(over="ignore"):
-        idx = np.arange(4 * n, dtype=np.uint64) + np.uint64(1)
+        idx = np.arange(4 * n, dtype=np.uint64) + np.uint64(4 * first + 1)
         z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
@@ -66,22 +73,75 @@ def splitmix_scalars(n, seed):
     return limbs.tobytes()
 
 
-def fr_dot_arith(scalars, first, n):
-    """sum_i k_i * (S0 + (first+i)*DSTEP) mod r  =  S0*sum(k_i) + DSTEP*sum((first+i)*k_i), exact, vectorised:
-    the scalars are split into 16-bit digits so that every numpy partial sum stays below 2^64."""
-    k16 = np.frombuffer(scalars, dtype=np.uint16).reshape(n, 16).astype(np.uint64)       # little-endian 16-bit digits
-    idx = np.arange(n, dtype=np.uint64)
-    ilo, ihi = idx & np.uint64(0xFFFF), idx >> np.uint64(16)                             # n <= 2^32
+def dlog_expect(d_scal, first, n):
+    """sum_i k_i * (S0 + (first+i)*DSTEP) mod r  =  S0*sum(k_i) + DSTEP*sum((first+i)*k_i), exact: the scalars (a CUDA uint8
+    tensor of n x 32 B) are split into 16-bit digits so that every int64 partial sum stays below 2^63; chunked on the device."""
+    import torch
     sum_k = 0; sum_ik = 0
-    for j in range(16):
-        col = k16[:, j]
-        sj = int(col.sum(dtype=np.uint64))                      # < 2^16 * n
-        lo = int((col * ilo).sum(dtype=np.uint64))              # < 2^32 * n  (n <= 2^31)
-        hi = int((col * ihi).sum(dtype=np.uint64))
-        sum_k += sj << (16 * j)
-        sum_ik += (lo + (hi << 16)) << (16 * j)
+    CH = 1 << 22
+    for c0 in range(0, n, CH):
+        m = min(CH, n - c0)
+        k16 = d_scal[32 * c0:32 * (c0 + m)].view(torch.int16).view(m, 16).to(torch.int64) & 0xFFFF
+        idx = torch.arange(c0, c0 + m, dtype=torch.int64, device=d_scal.device)
+        ilo, ihi = (idx & 0xFFFF).unsqueeze(1), (idx >> 16).unsqueeze(1)            # n <= 2^31
+        sj = k16.sum(0).tolist()                                                    # < 2^16 * 2^22
+        lo = (k16 * ilo).sum(0).tolist()                                            # < 2^32 * 2^22
+        hi = (k16 * ihi).sum(0).tolist()
+        for j in range(16):
+            sum_k += sj[j] << (16 * j)
+            sum_ik += (lo[j] + (hi[j] << 16)) << (16 * j)
     tot = (S0 * sum_k + DSTEP * (sum_ik + first * sum_k)) % R_MOD
     return tot.to_bytes(32, "little")
+
+
+def self_launch(ngpus):
+    """python bench.py --gpus N without a launcher: start the N ranks as children (nothing here has touched the GPU yet)"""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def kernel_avgs(prof):
+    return {k: round(ms / max(cnt, 1), 4) for k, (ms, cnt) in prof.items()}
+
+
+def hbm_roofline(alg_bytes, kernel, kernel_ms, traffic=None, extra=None):
+    """traffic: None or (HBM bytes per launch, source) from stored_traffic()"""
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else None
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic[0] if traffic else None,
+         "kernel_avg_ms": round(kernel_ms, 4) if kernel_ms else None, "algorithmic_bytes_per_launch": int(alg_bytes)}
+    if traffic:
+        r["traffic_source"] = traffic[1] + " (stored rocprofv3 --pmc passes of this workload at this size: FETCH_SIZE x 2 + WRITE_SIZE per the gfx950 correction; not measured by this run)"
+    if extra:
+        r.update(extra)
+    return r
+
+
+def stored_traffic(workload, size_key, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), only when the
+    stored entry was measured at exactly this workload size; otherwise None (never a number from another size)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        for e in json.load(open(path)).get("entries", []):
+            if e.get("workload") == workload and e.get("size") == size_key and e.get("kernel") == kernel:
+                return (e["hbm_bytes_per_launch"], e.get("source", "profiles/pmc_traffic.json"))
+    except Exception:
+        pass
+    return None
+
+
+class Timer:
+    def __init__(self, barrier):
+        self.barrier = barrier
+
+    def run(self, fn, steps):
+        self.barrier(); t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return time.perf_counter() - t0
 
 
 def main():
@@ -89,17 +149,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--workload", choices=["msm", "hyrax"], default="msm")
-    ap.add_argument("--log-n", type=int, default=20, help="msm: log2 of the points per GPU")
-    ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows per GPU")
+    ap.add_argument("--workload", choices=["msm", "hyrax"], default="msm", help="which workload is the HEADLINE value (msm = BASELINE configs[1])")
+    ap.add_argument("--log-n", type=int, default=20, help="msm headline: log2 of the points per GPU")
+    ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows")
     ap.add_argument("--cols", type=int, default=8192, help="hyrax: matrix columns")
-    ap.add_argument("--inflight", type=int, default=4, help="independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
-    ap.add_argument("--fixed-base", action="store_true", help="msm: treat the resident bases as fixed generators (per-window multiples precomputed once, "
-                    "as the commit path does): sbn_commit_rows with L = 1 instead of sbn_msm_bases")
+    ap.add_argument("--inflight", type=int, default=4, help="headline: independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
+    ap.add_argument("--blocks", default="all", help="extra blocks: all | none | comma list of hyrax,sweep,sumcheck")
+    ap.add_argument("--sweep", default="22,24,26", help="msm_sweep sizes (log2) on one GPU")
+    ap.add_argument("--strong-log-n", type=int, default=26, help="N > 1: log2 of the FIXED total size of the strong-scaling MSM (config 4)")
+    ap.add_argument("--sc-log-n", type=int, default=21, help="sumcheck block: log2 of the table length")
     ap.add_argument("--const-tail", type=float, default=0.0, help="hyrax: fraction of each 512-row block whose rows repeat one constant "
                     "(the padded tail of every derefs matrix repeats mem[0], sparse_mlpoly_full.rs:89-101; ~0.43 at keyless size)")
     ap.add_argument("--precompute-gb", type=float, default=100.0, help="hyrax: HBM budget (GiB) of the fixed-base lookup table of the generator set "
-                    "(sbn_bases_precompute; built once before the timed region like any commitment-key setup); 0 = bucket method")
+                    "(sbn_bases_precompute; built once before the timed region like any commitment-key setup); 0 = bucket method only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,9 +169,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np  # noqa: F401
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_pkg
+
     # BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices and the
     # 64-byte partials travel as CPU tensors); the driver's runs use the default: "nccl", which is RCCL on ROCm.
     backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -131,6 +199,7 @@ def main():
     ctx = sbn.Context(dev_index)    # raises if the HIP library / device is missing: no fallback
     M = max(1, args.inflight)
     ctxs = [ctx] + [sbn.Context(dev_index) for _ in range(M - 1)]     # one HIP stream + workspace per step in flight
+    blocks = set() if args.blocks == "none" else ({"hyrax", "sweep", "sumcheck"} if args.blocks == "all" else set(args.blocks.split(",")))
 
     def barrier():
         if world > 1:
@@ -139,224 +208,419 @@ def main():
         for cx in ctxs:
             cx.sync()
 
-    G_XY = bytes([1]) + bytes(31) + bytes([2]) + bytes(31)
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    timer = Timer(barrier)
+
+    def synth_scalars(n, first):
+        t = torch.empty(32 * n, dtype=torch.uint8, device=dev)
+        ctx.scalars_synthetic(SEED, first, n, t.data_ptr())
+        return t
+
+    def fold_partials(parts):
+        """one all-gather for the partial sums of the steps that just completed, then the local folds"""
+        if world == 1:
+            return parts
+        xy, _ = zip(*parts)
+        t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(coll_dev)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        allb = [o.cpu().numpy().tobytes() for o in outs]
+        return [sbn.g1_sum(b"".join(a[64 * j:64 * j + 64] for a in allb)) for j in range(len(parts))]
+
+    # ------------------------------------------------------------------------------------------------ one MSM problem
+    def msm_problem(n, first):
+        """bases P_i = (S0 + (first+i) DSTEP) G, scalars from the SplitMix64 stream at offset `first`, the expected partial sum"""
+        d_scal = synth_scalars(n, first)
+        bases = ctx.bases_synthetic(n, first, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+        want = ol.g1_mul(G_XY, dlog_expect(d_scal, first, n))
+        return d_scal, bases, want
+
+    def check_sharded(total, want):
+        """the folded result must be the sum of all ranks' expectations"""
+        if world == 1:
+            return total == want
+        wants = [None] * world
+        dist.all_gather_object(wants, want)
+        return total == sbn.g1_sum(b"".join(wants))[0]
+
+    def timed_msm(cx_list, d_scal, bases, n, steps, warm):
+        """`steps` MSMs, one in flight on cx_list[0] when len == 1, else shared out over the streams; returns (seconds, profile)"""
+        from concurrent.futures import ThreadPoolExecutor
+        Mx = len(cx_list)
+        pool = ThreadPoolExecutor(max_workers=Mx) if Mx > 1 else None
+
+        def local(cx):
+            return cx.msm_bases_dev(bases, d_scal.data_ptr(), n)
+
+        def run(count):
+            if Mx == 1:
+                for _ in range(count):
+                    fold_partials([local(cx_list[0])])
+                return
+            if world == 1:
+                shares = [count // Mx + (1 if j < count % Mx else 0) for j in range(Mx)]
+                futs = [pool.submit(lambda cx=cx, k=k: [local(cx) for _ in range(k)]) for cx, k in zip(cx_list, shares)]
+                for f in futs:
+                    f.result()
+                return
+            done = 0
+            while done < count:                   # rounds of up to 4 steps per stream, then ONE all-gather carrying all their partials
+                g = min(4 * Mx, count - done)
+                shares = [g // Mx + (1 if j < g % Mx else 0) for j in range(Mx)]
+                futs = [pool.submit(lambda cx=cx, k=k: [local(cx) for _ in range(k)]) for cx, k in zip(cx_list, shares) if k]
+                fold_partials([p for f in futs for p in f.result()])
+                done += g
+
+        for cx in cx_list:                        # every stream's workspace is sized before the timed region
+            local(cx)
+        run(warm)
+        for cx in cx_list:
+            cx.prof_enable(True); cx.prof_reset()
+        barrier(); t0 = time.perf_counter()
+        run(steps)
+        barrier(); dt = time.perf_counter() - t0
+        prof = {}
+        for cx in cx_list:
+            for k, (ms, cnt) in cx.prof_get().items():
+                a, b = prof.get(k, (0.0, 0)); prof[k] = (a + ms, b + cnt)
+            cx.prof_enable(False)
+        if pool:
+            pool.shutdown()
+        return max_over_ranks(dt), prof
+
+    def msm_alu(job, kernel_ms):
+        madds = job["slots"]                      # uniform scalars: a digit is zero with probability 2^-c
+        return {"unit": "mixed additions/s", "achieved": round(madds / (kernel_ms * 1e-3), 1), "peak": MADD_PEAK, "frac": round(madds / (kernel_ms * 1e-3) / MADD_PEAK, 4),
+                "window_bits": job["c"], "windows": job["W"], "mixed_additions_per_launch": int(madds),
+                "note": "peak = xyzz_madd in registers, all CUs busy (tools/micro/ecbench.hip); kernel time from the one-step-in-flight pass"}
+
+    # ------------------------------------------------------------------------------------------------ Hyrax matrices
+    def hyrax_setup(L, Rc):
+        bases, _ = ctx.gens_new(Rc, b"gens_r1cs_eval", want_points=False)    # the reference's gens_derefs set (sparse_mlpoly_full.rs:625-627)
+        Z = synth_scalars(L * Rc, 1 << 40)                                   # uniform in Fr, full width
+        Zv = Z.view(L, Rc * 32)
+        Zv[(3 * L // 4):] = 0                                                # rows 3072.. are zero padding (hyrax.rs:245)
+        if args.const_tail > 0:                                              # SURVEY 8d config 3 variant: constant suffix of every 512-row block
+            blk = max(1, L // 8)
+            for b0 in range(0, 3 * L // 4, blk):
+                k0 = b0 + int(blk * (1.0 - args.const_tail))
+                Zv[k0:b0 + blk] = Zv[k0:k0 + 1, :32].repeat(1, Rc)
+        torch.cuda.synchronize()
+        return bases, Z
+
+    def hyrax_check(Z, out, L, Rc, rows, gxy):
+        Zv = Z.view(L, Rc * 32)
+        for i in rows:
+            row = Zv[i].cpu().numpy().tobytes()
+            if out[64 * i:64 * i + 64] != ol.commit(row, bytes(32), gxy[:64 * Rc], gxy[64 * Rc:]):
+                return i
+        return None
+
+    line_extra = {}
     cpu_baseline = None
+    # ================================================================================================ headline
     if args.workload == "msm":
         n = 1 << args.log_n
         first = rank * n                                           # this rank's base-point range of the N*n-point MSM
-        scal = splitmix_scalars(n, 0x5BA27A2B4E254 + 7919 * rank)
-        d_scal = torch.frombuffer(bytearray(scal), dtype=torch.uint8).to(dev)
-        bases = ctx.bases_synthetic(n, first, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
-        torch.cuda.synchronize()
-
-        def local_step(cx):
-            if args.fixed_base:
-                xy, infs = cx.commit_rows_dev(bases, d_scal.data_ptr(), 0, 1, n)
-                return xy, bool(infs[0])
-            return cx.msm_bases_dev(bases, d_scal.data_ptr(), n)
-
-        def finish(parts):
-            """one RCCL all-gather for the partial sums of the steps that just completed, then the local folds"""
-            if world == 1:
-                return parts
-            xy, _ = zip(*parts)
-            t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(coll_dev)
-            outs = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(outs, t)
-            allb = [o.cpu().numpy().tobytes() for o in outs]
-            return [sbn.g1_sum(b"".join(a[64 * j:64 * j + 64] for a in allb)) for j in range(len(parts))]
-
-        def step():
-            return finish([local_step(ctx)])[0]
-
-        # parity gate: partial == (sum k_i s_i) G, exact
-        part, _ = local_step(ctx)
-        want = ol.g1_mul(G_XY, fr_dot_arith(scal, first, n))
+        d_scal, bases, want = msm_problem(n, first)
+        part, _ = ctx.msm_bases_dev(bases, d_scal.data_ptr(), n)   # parity gate: partial == (sum k_i s_i) G, exact
         if part != want:
             raise SystemExit(f"rank {rank}: GPU MSM result differs from the discrete-log oracle")
-        total, _ = step()
-        if world > 1:                                             # the folded result must be the sum of all ranks' expectations
-            wants = [None] * world
-            dist.all_gather_object(wants, want)
-            if total != sbn.g1_sum(b"".join(wants))[0]:
-                raise SystemExit("sharded MSM result differs from the folded oracle partials")
+        total = fold_partials([(part, False)])[0][0]
+        if not check_sharded(total, want):
+            raise SystemExit("sharded MSM result differs from the folded oracle partials")
+        dt, prof = timed_msm(ctxs, d_scal, bases, n, args.steps, args.warmup)
+        serial = None
+        ns_ser = max(2, min(16, args.steps))
+        ts, sp = timed_msm([ctx], d_scal, bases, n, ns_ser, 1)
+        serial = {"steps": ns_ser, "ms_per_step": round(ts / ns_ser * 1e3, 4), "kernels_avg_ms": kernel_avgs(sp)}
         units_per_step = n
-        alg_bytes_per_launch = 96.0 * n                            # SURVEY 8d: 32 B scalar + 64 B affine base per point
-        active_fraction = 1.0                                      # uniform scalars: a digit is zero with probability 2^-c
         dominant = "k_acc_first"
-        workload = f"synthetic BN254 G1 MSM, 2^{args.log_n} uniform scalars x distinct bases per GPU, inputs resident in HBM" + (
-            " (fixed-base mode: per-window multiples of the bases precomputed once)" if args.fixed_base else "")
-        metric = "msm_points_per_s"
-        unit = "points/s"
+        dom_ms = serial["kernels_avg_ms"].get(dominant, 0.0)
+        roofline = hbm_roofline(96.0 * n, dominant, dom_ms, stored_traffic("msm", f"2^{args.log_n}", dominant),
+                                {"note": "kernel time from the one-step-in-flight pass (with several streams a launch shares the chip and its event-to-event time "
+                                         "stretches); MSM is integer-ALU bound (~170 modular products per point vs 96 B): see roofline.alu and DESIGN.md"})
+        if M > 1:
+            pm, pc = prof.get(dominant, (0.0, 0))
+            roofline["inflight_pass_kernel_avg_ms"] = round(pm / max(pc, 1), 4)
+        if dom_ms:
+            roofline["alu"] = msm_alu(ctx.prof_last_job(), dom_ms)
+        workload = f"synthetic BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x distinct bases per GPU, inputs resident in HBM"
+        sharding_desc = "base-point ranges + one RCCL all-gather of 64-B partial sums"
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cores = min(len(os.sched_getaffinity(0)), 16)
+            ns = min(n, 1 << 20); n1 = min(n, 1 << 18)
+            pts = ctx.bases_download(bases, 0, ns)
+            sc_host = d_scal[:32 * ns].cpu().numpy().tobytes()
+            tb = time.perf_counter(); got = ol.msm_pippenger(sc_host, pts, cores); tcpu = time.perf_counter() - tb
+            if ns == n and got != want:
+                raise SystemExit("CPU oracle and GPU disagree")
+            tb = time.perf_counter(); ol.msm_pippenger(sc_host[:32 * n1], pts[:64 * n1], 1); t1 = time.perf_counter() - tb
+            cpu_baseline = {"value": round(ns / tcpu, 1), "unit": "points/s", "cores": cores, "kind": "port",
+                            "sample": f"the same MSM on its first 2^{ns.bit_length() - 1} points: oracle/ arkworks-style signed-digit Pippenger (c={ol.window_bits(ns)}), threads over windows",
+                            "one_thread": {"value": round(n1 / t1, 1), "unit": "points/s", "cores": 1,
+                                           "sample": f"first 2^{n1.bit_length() - 1} points, 1 thread (the published RAYON_NUM_THREADS=1 configuration, reference README.md:29-35); c={ol.window_bits(n1)}"}}
+        bases.free(); del d_scal
     else:
         L, Rc = args.rows, args.cols
-        bases, _ = ctx.gens_new(Rc, b"gens_r1cs_eval", want_points=False)    # the reference's gens_derefs set (sparse_mlpoly_full.rs:625-627)
+        bases, Z = hyrax_setup(L, Rc)
         comb_c = 0
         if args.precompute_gb > 0:
-            tpre = time.perf_counter()
             try:
                 comb_c = ctx.bases_precompute(bases, int(args.precompute_gb * (1 << 30)))
             except sbn.SbnError as e:                              # e.g. another tenant holds the HBM: keep the bucket method
                 print(f"[bench] precompute skipped: {e}", file=sys.stderr)
-            tpre = time.perf_counter() - tpre
-        g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
-        Z = torch.randint(0, 2**31 - 1, (L * Rc, 8), dtype=torch.int32, device=dev, generator=g)
-        Z[:, 7] &= 0x0fffffff                                     # canonical (< 2^252)
-        Z[(3 * L // 4) * Rc:] = 0                                  # rows 3072.. are zero padding (hyrax.rs:245)
-        if args.const_tail > 0:                                    # SURVEY 8d config 3 variant: constant suffix of every 512-row block
-            blk = max(1, L // 8)
-            for b0 in range(0, 3 * L // 4, blk):
-                k0 = b0 + int(blk * (1.0 - args.const_tail))
-                Z[k0 * Rc:(b0 + blk) * Rc] = Z[k0 * Rc]
-        torch.cuda.synchronize()
+        # ONE matrix; with N > 1 every rank commits its interleaved rows and the commitments are joined with gather_rows
+        my_rows = sharding.shard_rows(L, rank, world)
+        Zl = Z.view(L, Rc * 32)[rank::world].contiguous() if world > 1 else Z
+        nl = len(my_rows)
 
-        def local_step(cx):
-            return cx.commit_rows_dev(bases, Z.data_ptr(), 0, L, Rc)
+        def hy_step():
+            out, _ = ctx.commit_rows_dev(bases, Zl.data_ptr(), 0, nl, Rc)
+            return sharding.gather_rows(out, L, rank, world, device=coll_dev) if world > 1 else out
 
-        def finish(parts):
-            return parts
-
-        def step():
-            return local_step(ctx)
-
-        out, infs = step()
+        out = hy_step()
         gxy, _ = ol.gens_new(Rc, b"gens_r1cs_eval")
-        for i in (0, L // 2, 3 * L // 4 - 1, L - 1):
-            row = Z[i * Rc:(i + 1) * Rc].cpu().numpy().tobytes()
-            if out[64 * i:64 * i + 64] != ol.commit(row, bytes(32), gxy[:64 * Rc], gxy[64 * Rc:]):
-                raise SystemExit(f"rank {rank}: Hyrax row {i} differs from the oracle")
-        units_per_step = L * Rc
-        alg_bytes_per_launch = L * Rc * 32.0 + (Rc + 1) * 64.0 + L * 64.0     # SURVEY 8d: 32.02 B/pair at 4096 x 8192
-        active_fraction = 0.75 * (1.0 - args.const_tail)           # zero rows and constant rows add (almost) nothing to the buckets
-        dominant = "k_comb_rows" if comb_c else "k_acc_first"
-        workload = f"Hyrax derefs commitment shape: {L} x {Rc} scalars per GPU, {Rc}+1 shared reference generators, last quarter of rows zero, inputs resident in HBM" + (
-            f", fixed-base lookup table c={comb_c} (built once in {tpre:.2f} s)" if comb_c else ", bucket method") + (
-            f", constant tail {args.const_tail:.2f} of every {max(1, L // 8)}-row block" if args.const_tail > 0 else "")
-        metric = "msm_points_per_s"
-        unit = "points/s"
-
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=M)
-
-    def run_steps(count):
-        """`count` steps with up to M in flight.  N = 1: each stream free-runs its share.  N > 1: rounds of up to 4*M local steps,
-        then one collective per round issued from this thread (collectives must be ordered identically on every rank)."""
-        if M == 1:
-            for _ in range(count):
-                step()
-            return
-        if world == 1:
-            shares = [count // M + (1 if j < count % M else 0) for j in range(M)]
-            futs = [pool.submit(lambda cx=cx, k=k: [local_step(cx) for _ in range(k)]) for cx, k in zip(ctxs, shares)]
-            for f in futs:
-                f.result()
-            return
-        done = 0
-        while done < count:                       # rounds of up to 4 steps per stream, then ONE all-gather carrying all their partials
-            g = min(4 * M, count - done)
-            shares = [g // M + (1 if j < g % M else 0) for j in range(M)]
-            futs = [pool.submit(lambda cx=cx, k=k: [local_step(cx) for _ in range(k)]) for cx, k in zip(ctxs, shares) if k]
-            finish([p for f in futs for p in f.result()])
-            done += g
-
-    for cx in ctxs:                       # every stream's workspace is sized before the timed region
-        local_step(cx)
-    run_steps(args.warmup)
-    for cx in ctxs:
-        cx.prof_enable(True); cx.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = {}
-    for cx in ctxs:
-        for k, (ms, cnt) in cx.prof_get().items():
-            a, b = prof.get(k, (0.0, 0)); prof[k] = (a + ms, b + cnt)
-        cx.prof_enable(False)
-    # serial reference: a few steps one at a time on one stream — the latency of a single call and per-kernel durations that
-    # are not stretched by other streams' kernels running beside them
-    serial = None
-    if M > 1:
-        ns_ser = max(2, min(16, args.steps))
+        bad = hyrax_check(Z, out, L, Rc, (0, 1, L // 2, 3 * L // 4 - 1, L - 1), gxy) if rank == 0 else None
+        if bad is not None:
+            raise SystemExit(f"Hyrax row {bad} differs from the oracle")
+        for _ in range(args.warmup):
+            hy_step()
         ctx.prof_enable(True); ctx.prof_reset()
-        barrier(); ts0 = time.perf_counter()
-        for _ in range(ns_ser):
-            step()
-        barrier(); ts = time.perf_counter() - ts0
-        sp = ctx.prof_get(); ctx.prof_enable(False)
-        serial = {"steps": ns_ser, "ms_per_step": round(ts / ns_ser * 1e3, 4), "kernels_avg_ms": {k: round(ms / max(cnt, 1), 4) for k, (ms, cnt) in sp.items()}}
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(timer.run(hy_step, args.steps))
+        prof = ctx.prof_get(); ctx.prof_enable(False)
+        serial = {"steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 4), "kernels_avg_ms": kernel_avgs(prof)}
+        units_per_step = L * Rc / world
+        dominant = "k_comb_rows" if comb_c else "k_acc_first"
+        alg = nl * Rc * 32.0 + (Rc + 1) * 64.0 + nl * 64.0
+        roofline = hbm_roofline(alg, dominant, serial["kernels_avg_ms"].get(dominant, 0.0), stored_traffic("hyrax-lookup" if comb_c else "hyrax-bucket", f"{L}x{Rc}", dominant) if world == 1 else None)
+        workload = f"Hyrax derefs commitment: ONE {L} x {Rc} matrix of uniform Fr scalars, {Rc}+1 shared reference generators, last quarter of rows zero, inputs resident in HBM" + (
+            f", fixed-base lookup table c={comb_c}" if comb_c else ", bucket method")
+        sharding_desc = "interleaved rows of one matrix per rank, joined by one all-gather of the row commitments; no data-path reduction"
+        M = 1
+        bases.free(); del Z, Zl
 
-    if rank == 0:
-        value = units_per_step * world * args.steps / dt
-        kern = {k: round(ms / max(cnt, 1), 4) for k, (ms, cnt) in prof.items()}
-        dom_ms, dom_cnt = prof.get(dominant, (0.0, 0))
-        dom_avg_ms = dom_ms / max(dom_cnt, 1)
-        achieved = alg_bytes_per_launch / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else None
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # HBM bytes/launch from separate rocprofv3 --pmc passes
-        if os.path.exists(pmc_path):
-            try:
-                per_kernel = json.load(open(pmc_path)).get(args.workload, {})
-                traffic = per_kernel.get(dominant)
-                if traffic is None:                     # template instances are recorded as name<args>: take the busiest one
-                    inst = [v for k, v in per_kernel.items() if k.startswith(dominant + "<")]
-                    traffic = max(inst) if inst else None
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None, "traffic": traffic,
-                    "kernel_avg_ms": round(dom_avg_ms, 4),
-                    "note": "MSM is integer-ALU bound (~170 modular products per point vs 96 B): see DESIGN.md for the ALU roofline"}
-        # the bound that actually applies: mixed additions per second of the accumulate kernel against the in-register
-        # ceiling measured by tools/micro/ecbench.hip on MI355X (every slot of a non-zero digit is one 8M+2S mixed addition)
-        job = ctx.prof_last_job()
-        madds = job["slots"] * active_fraction
-        ref_ms = serial["kernels_avg_ms"].get(dominant) if serial else dom_avg_ms
-        if ref_ms:
-            roofline["alu"] = {"unit": "mixed additions/s", "achieved": round(madds / (ref_ms * 1e-3), 1), "peak": MADD_PEAK, "frac": round(madds / (ref_ms * 1e-3) / MADD_PEAK, 4),
-                               "window_bits": job["c"], "windows": job["W"], "mixed_additions_per_launch": int(madds),
-                               "note": "peak = xyzz_madd in registers, all CUs busy (tools/micro/ecbench.hip: 1.2e10/s = 1.29e11 Montgomery products/s); kernel time from the one-step-in-flight pass"}
-        if serial and serial["kernels_avg_ms"].get(dominant):
-            sa = alg_bytes_per_launch / (serial["kernels_avg_ms"][dominant] * 1e-3) / 1e9
-            roofline["serial_pass"] = {"kernel_avg_ms": serial["kernels_avg_ms"][dominant], "achieved": round(sa, 2), "frac": round(sa / HBM_PEAK_GBS, 5),
-                                       "note": "same kernel with ONE step in flight: with several streams a launch shares the chip, so its event-to-event time is longer"}
-        if not args.no_cpu_baseline and world == 1:
-            cores = min(len(os.sched_getaffinity(0)), 16)
-            if args.workload == "msm":
-                ns = min(n, 1 << 20)
-                pts = ctx.bases_download(bases, 0, ns)
-                tb = time.perf_counter(); got = ol.msm_pippenger(scal[:32 * ns], pts, cores); tcpu = time.perf_counter() - tb
-                if ns == n and got != want:
-                    raise SystemExit("CPU oracle and GPU disagree")
-                cpu_baseline = {"value": round(ns / tcpu, 1), "unit": unit, "cores": cores, "kind": "port",
-                                "sample": f"the same MSM on its first 2^{ns.bit_length() - 1} points: oracle/ arkworks-style signed-digit Pippenger (c={ol.window_bits(ns)}), threads over windows"}
-            else:
+    value = units_per_step * world * args.steps / dt
+
+    # ================================================================================================ extra blocks
+    torch.cuda.empty_cache()
+    if "hyrax" in blocks and args.workload == "msm":
+        L, Rc = args.rows, args.cols
+        try:
+            hb, Z = hyrax_setup(L, Rc)
+            gxy, _ = ol.gens_new(Rc, b"gens_r1cs_eval") if rank == 0 else (None, None)
+            my_rows = sharding.shard_rows(L, rank, world)
+            Zl = Z.view(L, Rc * 32)[rank::world].contiguous() if world > 1 else Z
+            nl = len(my_rows)
+            res = {"shape": f"{L}x{Rc}", "scalars": "uniform in Fr (SplitMix64 mod r), rows >= 3L/4 zero", "generators": "MultiCommitGens::new(8192, b'gens_r1cs_eval') (commitments.rs:31-62): 2813 unique points + h",
+                   "rows_per_rank": nl, "sharding": "interleaved rows of ONE matrix, gather_rows" if world > 1 else None,
+                   "algorithmic_bytes_per_pair": round((L * Rc * 32.0 + (Rc + 1) * 64.0 + L * 64.0) / (L * Rc), 3)}
+
+            def hy_step():
+                out, _ = ctx.commit_rows_dev(hb, Zl.data_ptr(), 0, nl, Rc)
+                return sharding.gather_rows(out, L, rank, world, device=coll_dev) if world > 1 else out
+
+            variants = [("bucket", 0.0)] + ([("lookup", args.precompute_gb)] if args.precompute_gb > 0 else [])
+            for name, gb in variants:                      # bucket first: the lookup table stays attached to the handle once built
+                comb_c = 0; tpre = 0.0
+                if gb > 0:
+                    tpre = time.perf_counter()
+                    try:
+                        comb_c = ctx.bases_precompute(hb, int(gb * (1 << 30)))
+                    except sbn.SbnError as e:
+                        res[name] = {"skipped": str(e)}; continue
+                    tpre = time.perf_counter() - tpre
+                out = hy_step()
+                bad = hyrax_check(Z, out, L, Rc, (0, 7, L // 2 + 1, 3 * L // 4 - 1, 3 * L // 4, L - 1), gxy) if rank == 0 else None
+                if bad is not None:
+                    raise SystemExit(f"hyrax[{name}]: row {bad} differs from the oracle")
+                hy_step()
+                ksteps = max(3, min(10, args.steps))
+                ctx.prof_enable(True); ctx.prof_reset()
+                hdt = max_over_ranks(timer.run(hy_step, ksteps))
+                hp = kernel_avgs(ctx.prof_get()); ctx.prof_enable(False)
+                dom = "k_comb_rows" if comb_c else "k_acc_first"
+                alg = nl * Rc * 32.0 + (Rc + 1) * 64.0 + nl * 64.0
+                job = ctx.prof_last_job()
+                r = {"ms_per_step": round(hdt / ksteps * 1e3, 4), "pairs_per_s": round(L * Rc * ksteps / hdt, 1), "steps": ksteps, "window_bits": job["c"],
+                     "parity": "6 sampled rows (first, zero-padding, last non-zero) bit-exact vs the CPU oracle",
+                     "roofline": hbm_roofline(alg, dom, hp.get(dom, 0.0), stored_traffic("hyrax-" + name, f"{L}x{Rc}", dom) if world == 1 else None),
+                     "kernels_avg_ms": hp}
+                if hp.get(dom):
+                    madds = 0.75 * job["slots"] * (1.0 - args.const_tail)          # zero rows add nothing
+                    r["roofline"]["alu"] = {"unit": "mixed additions/s", "achieved": round(madds / (hp[dom] * 1e-3), 1), "peak": MADD_PEAK, "frac": round(madds / (hp[dom] * 1e-3) / MADD_PEAK, 4)}
+                if comb_c:
+                    r["lookup_table"] = {"window_bits": comb_c, "build_s": round(tpre, 2)}
+                res[name] = r
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                cores = min(len(os.sched_getaffinity(0)), 16)
                 rows = min(L, 2 * cores)
-                Zs = Z[:rows * Rc].cpu().numpy().tobytes()
+                Zs = Z[:rows * Rc * 32].cpu().numpy().tobytes()
                 tb = time.perf_counter(); got = ol.commit_rows(Zs, None, rows, Rc, gxy[:64 * Rc], gxy[64 * Rc:], cores); tcpu = time.perf_counter() - tb
                 if got != out[:64 * rows]:
-                    raise SystemExit("CPU oracle and GPU disagree")
-                cpu_baseline = {"value": round(rows * Rc / tcpu, 1), "unit": unit, "cores": cores, "kind": "port",
-                                "sample": f"first {rows} rows of the same matrix: oracle/ per-row Pippenger, threads over rows (hyrax.rs:259-261)"}
-        line = {"metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    raise SystemExit("CPU oracle and GPU disagree (hyrax rows)")
+                tb = time.perf_counter(); ol.commit_rows(Zs[:2 * Rc * 32], None, 2, Rc, gxy[:64 * Rc], gxy[64 * Rc:], 1); t1 = time.perf_counter() - tb
+                res["cpu_baseline"] = {"value": round(rows * Rc / tcpu, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
+                                       "sample": f"first {rows} rows of the same matrix: oracle/ per-row Pippenger, threads over rows (hyrax.rs:259-261)",
+                                       "one_thread": {"value": round(2 * Rc / t1, 1), "unit": "pairs/s", "cores": 1, "sample": "first 2 rows, 1 thread; the reference publishes 166.2 s for the whole commitment on one M2 Max core (BENCHMARK_RESULTS.md:37-39)"}}
+            line_extra["hyrax"] = res
+            hb.free(); del Z, Zl
+        except (sbn.SbnError, RuntimeError) as e:
+            line_extra["hyrax"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
+    if "sweep" in blocks and args.workload == "msm":
+        sweep = {}
+        if world == 1:
+            for ln in [int(x) for x in args.sweep.split(",") if x]:
+                try:
+                    nn = 1 << ln
+                    ds, bs, wt = msm_problem(nn, 0)
+                    got, _ = ctx.msm_bases_dev(bs, ds.data_ptr(), nn)
+                    if got != wt:
+                        raise SystemExit(f"msm_sweep 2^{ln}: GPU result differs from the discrete-log oracle")
+                    ksteps = 12 if ln <= 22 else 6 if ln <= 24 else 3
+                    sdt, sp = timed_msm([ctx], ds, bs, nn, ksteps, 1)
+                    ka = kernel_avgs(sp)
+                    e = {"ms_per_step": round(sdt / ksteps * 1e3, 4), "points_per_s": round(nn * ksteps / sdt, 1), "steps": ksteps, "steps_in_flight": 1,
+                         "parity": "bit-exact vs the discrete-log identity", "kernels_avg_ms": ka,
+                         "roofline": hbm_roofline(96.0 * nn, "k_acc_first", ka.get("k_acc_first", 0.0), stored_traffic("msm", f"2^{ln}", "k_acc_first"))}
+                    if ka.get("k_acc_first"):
+                        e["roofline"]["alu"] = msm_alu(ctx.prof_last_job(), ka["k_acc_first"])
+                    sweep[f"2^{ln}"] = e
+                    bs.free(); del ds
+                    torch.cuda.empty_cache()
+                except sbn.SbnError as e:
+                    sweep[f"2^{ln}"] = {"error": str(e)}
+        else:
+            # config 4: ONE MSM of 2^strong_log_n points, cut into `world` base-point ranges (strong scaling)
+            ntot = 1 << args.strong_log_n
+            lo, hi = sharding.shard_range(ntot, rank, world)
+            nn = hi - lo
+            ds, bs, wt = msm_problem(nn, lo)
+            part, _ = ctx.msm_bases_dev(bs, ds.data_ptr(), nn)
+            if part != wt:
+                raise SystemExit(f"rank {rank}: strong-scaling partial differs from the discrete-log oracle")
+            total = fold_partials([(part, False)])[0][0]
+            if not check_sharded(total, wt):
+                raise SystemExit("strong-scaling MSM: folded result differs from the folded oracle partials")
+            ksteps = 4
+            sdt, sp = timed_msm([ctx], ds, bs, nn, ksteps, 1)
+            sweep[f"2^{args.strong_log_n}_strong"] = {"total_points": ntot, "points_per_rank": nn, "n_gpus": world, "scaling": "strong", "ms_per_step": round(sdt / ksteps * 1e3, 4),
+                                                      "points_per_s": round(ntot * ksteps / sdt, 1), "steps": ksteps, "parity": "each partial and the folded sum bit-exact vs the discrete-log identity",
+                                                      "collective": f"one all-gather of {world} x 64 B per MSM ({backend})", "kernels_avg_ms": kernel_avgs(sp)}
+            bs.free(); del ds
+        line_extra["msm_sweep"] = sweep
+        torch.cuda.empty_cache()
+
+    if "sumcheck" in blocks and world == 1:
+        try:
+            line_extra["sumcheck"] = sumcheck_block(ctx, sbn, ol, torch, dev, args.sc_log_n)
+        except sbn.SbnError as e:
+            line_extra["sumcheck"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        line = {"metric": "msm_points_per_s", "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u32", "data": "synthetic",
-                "config": {"workload": workload, "units_per_step_per_gpu": units_per_step, "steps_in_flight": M, "collective_backend": backend if world > 1 else None,
-                           "sharding": "base-point ranges + one RCCL all-gather of 64-B partial sums" if args.workload == "msm" else "independent matrices per GPU, no collective",
-                           "parity": "bit-exact vs discrete-log oracle, checked before timing"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kern, "serial_reference": serial}
+                "config": {"workload": workload, "units_per_step_per_gpu": int(units_per_step), "steps_in_flight": M, "collective_backend": backend if world > 1 else None,
+                           "sharding": sharding_desc, "parity": "bit-exact vs the discrete-log identity / CPU oracle, checked before timing"},
+                "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kernel_avgs(prof), "serial_reference": serial}
+        line.update(line_extra)
         print(json.dumps(line), flush=True)
-    bases.free()
-    pool.shutdown()
     for cx in ctxs:
         cx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
+    """prove_cubic_batched, layer 0 of the ops product circuits (sumcheck.rs:165-330): 12 "par" instances sharing one C
+    table + 6 "seq" instances; fused bind+eval rounds.  Parity: round-0 sums of one par and one seq instance against the CPU
+    oracle, e0 + e1 = claim is implied by construction, and the fused rounds' final table values against the separate
+    eval / bind path on the same inputs."""
+    n = 1 << logn
+    NPAR, NSEQ = 12, 6
+    ntab = 2 * NPAR + 1 + 3 * NSEQ
+
+    def fresh():
+        ts = []
+        for k in range(ntab):
+            x = torch.empty(32 * n, dtype=torch.uint8, device=dev)
+            ctx.scalars_synthetic(SEED + 1000 + k, 0, n, x.data_ptr())
+            ts.append(ctx.table_from_dev(x.data_ptr(), n, 0)); del x
+        par_a, par_b, c_par = ts[:NPAR], ts[NPAR:2 * NPAR], ts[2 * NPAR]
+        rest = ts[2 * NPAR + 1:]
+        seq_a, seq_b, seq_c = rest[:NSEQ], rest[NSEQ:2 * NSEQ], rest[2 * NSEQ:]
+        return ts, par_a + seq_a, par_b + seq_b, [c_par] * NPAR + seq_c
+
+    def challenge(ev):
+        return (int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % R_MOD).to_bytes(32, "little")
+
+    res = {"workload": f"batched cubic sumcheck, {NPAR} par + {NSEQ} seq instances, tables of 2^{logn}, {logn} rounds, {round(ntab * n * 32 / 2**30, 2)} GiB in round 0"}
+    finals = {}
+    for mode in ("separate", "fused"):
+        times = []; prof = {}
+        reps = 2 if mode == "separate" else 3
+        for rep in range(reps):
+            ts, As, Bs, Cs = fresh()
+            if mode == "fused" and rep == 0:                       # parity gate on round 0 (one par, one seq instance) against the oracle
+                ev0 = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+                for inst in (0, NPAR):
+                    a, b, c_ = (ctx.table_download(t) for t in (As[inst], Bs[inst], Cs[inst]))
+                    if ev0[96 * inst:96 * inst + 96] != ol.sc_eval_cubic(a, b, c_):
+                        raise SystemExit(f"sumcheck block: round-0 sums of instance {inst} differ from the oracle")
+            ctx.prof_enable(True); ctx.prof_reset()
+            ctx.sync(); t0 = time.perf_counter()
+            ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+            for rnd in range(logn):
+                r = challenge(ev)
+                if mode == "fused" and len(ts[0]) >= 4:
+                    ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+                else:
+                    ctx.bind_top_many(ts, r)
+                    if len(ts[0]) >= 2:
+                        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+            ctx.sync(); dtm = time.perf_counter() - t0
+            prof = ctx.prof_get(); ctx.prof_enable(False)
+            finals[mode] = [ctx.table_read0(t) for t in ts]
+            for t in ts:
+                t.free()
+            if rep:
+                times.append(dtm)
+        res[mode] = {"ms_per_sumcheck": round(1e3 * sum(times) / len(times), 3), "kernels_ms_total": {k: round(v[0], 3) for k, v in prof.items()},
+                     "kernels_launches": {k: v[1] for k, v in prof.items()}}
+    if finals["separate"] != finals["fused"]:
+        raise SystemExit("sumcheck block: fused and separate rounds disagree on the final table values")
+    table_bytes = ntab * n * 32
+    # eval reads every live table once, a bind reads it once and writes half; live bytes halve per round (sum over rounds = 2 x round 0)
+    alg_sep = 2 * table_bytes * (1 + 1 + 0.5)
+    alg_first = table_bytes
+    alg_fused_rounds = 2 * table_bytes * (1 + 0.5)
+    for mode, alg in (("separate", alg_sep), ("fused", alg_first + alg_fused_rounds)):
+        ms = res[mode]["ms_per_sumcheck"]
+        res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
+        res[mode]["GBps_end_to_end"] = round(alg / (ms * 1e-3) / 1e9, 1)
+    kf = res["fused"]["kernels_ms_total"]
+    fused_ms = kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)     # the pre-bind of the shared C table belongs to the round
+    if fused_ms:
+        ach = alg_fused_rounds / (fused_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_bind_eval_cubic (+ k_bind_oop of the shared table)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                           "traffic": None, "kernel_ms_all_rounds": round(fused_ms, 3), "algorithmic_bytes_all_rounds": int(alg_fused_rounds),
+                           "note": "kernel-only: all fused rounds of one sumcheck (table bytes halve per round); 43 distinct tables read once, bound halves written once"}
+    ke = res["separate"]["kernels_ms_total"]
+    if ke.get("k_sc_eval_cubic") and ke.get("k_bind_top"):
+        res["separate"]["eval_GBps"] = round(2 * table_bytes / (ke["k_sc_eval_cubic"] * 1e-3) / 1e9, 1)
+        res["separate"]["bind_GBps"] = round(2 * table_bytes * 1.5 / (ke["k_bind_top"] * 1e-3) / 1e9, 1)
+    res["parity"] = "round-0 sums of one par and one seq instance bit-exact vs the CPU oracle; fused and separate paths agree on all 43 final values"
+    return res
 
 
 if __name__ == "__main__":

@@ -83,6 +83,10 @@ int sbn_gens_new(sbn_ctx* ctx, size_t n, const uint8_t* label, size_t label_len,
 /* Synthetic benchmark bases with known discrete logs: P_i = (s0 + (first + i) * d) * G for
  * i in [0, n), all distinct, built on the device; the expected MSM result is then (sum k_i (s0 + (first+i) d)) * G. */
 int sbn_bases_synthetic(sbn_ctx* ctx, size_t n, uint64_t first, const uint8_t s0[32], const uint8_t d[32], sbn_bases** out);
+/* Synthetic benchmark scalars, written to a DEVICE buffer of n x 32 B: scalar t = the SplitMix64 outputs of
+ * counters 4*(first+t)+1 .. +4 (state = seed + counter * 0x9E3779B97F4A7C15) as four little-endian u64 limbs, the top limb cut
+ * to 62 bits, minus r when >= r: canonical, full-width values of Fr (the same stream bench.py's numpy generator produces). */
+int sbn_scalars_synthetic(sbn_ctx* ctx, uint64_t seed, uint64_t first, size_t n, void* out_dev);
 /* copy `count` points starting at `first` back to the host as canonical x||y (for tests of resident tables) */
 int sbn_bases_download(sbn_ctx* ctx, const sbn_bases* b, size_t first, size_t count, uint8_t* out_xy);
 

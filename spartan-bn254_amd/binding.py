@@ -10,7 +10,7 @@ SBN_POINTS_MONT = 2
 EXPORTED_SYMBOLS = [
     "sbn_ctx_create", "sbn_ctx_destroy", "sbn_last_error", "sbn_ctx_set_stream", "sbn_ctx_sync", "sbn_version",
     "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
-    "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_precompute", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_bases_download",
+    "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_precompute", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_scalars_synthetic", "sbn_bases_download",
     "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_unipoly_from_evals", "sbn_unipoly_eval", "sbn_factored_lens",
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
@@ -232,6 +232,9 @@ class Context:
         hb = C.c_void_p()
         self._chk(lib().sbn_bases_synthetic(self.h, C.c_size_t(n), C.c_uint64(first), _ptr(s0), _ptr(d), C.byref(hb)), "sbn_bases_synthetic")
         return Bases(self, hb)
+
+    def scalars_synthetic(self, seed, first, n, out_dev_ptr):
+        self._chk(lib().sbn_scalars_synthetic(self.h, C.c_uint64(seed), C.c_uint64(first), C.c_size_t(n), C.c_void_p(out_dev_ptr)), "sbn_scalars_synthetic")
 
     def bases_download(self, bases, first, count):
         out = (C.c_uint8 * (64 * count))()

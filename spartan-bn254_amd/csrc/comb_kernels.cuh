@@ -69,6 +69,9 @@ __global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ 
     Affine p_prev; bool neg_prev = false, have = false;
     for (size_t col = (size_t)blockIdx.y * blockDim.x + threadIdx.x; col < a.n; col += (size_t)S * blockDim.x) {
       const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      { const uint4 q0 = reinterpret_cast<const uint4*>(k)[0], q1 = reinterpret_cast<const uint4*>(k)[1];
+        const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }      // scalar >= r: reported by the host wrapper, never summed silently
       uint32_t carry = 0;
       for (int w = 0; w < s.W; w++) {
         const int d = window_digit(k, w, s.c, carry);
@@ -95,6 +98,9 @@ __global__ void __launch_bounds__(64) k_comb_rows_const(const uint32_t* __restri
     for (int idx = lane; idx < n2; idx += 64) {
       const size_t col = idx < s.W ? col_a : col_b; const int w = idx < s.W ? idx : idx - s.W;
       const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      if (w == 0) { const uint4 q0 = reinterpret_cast<const uint4*>(k)[0], q1 = reinterpret_cast<const uint4*>(k)[1];
+        const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }      // scalar >= r: reported by the host wrapper, never summed silently
       const int d = window_digit_indep(k, w, s.c);
       if (d == 0) continue;
       const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
@@ -115,6 +121,9 @@ __global__ void __launch_bounds__(256) k_comb_rows_flat(const uint32_t* __restri
     for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += S * blockDim.x) {
       const uint32_t w = idx / ncol, col = idx - w * ncol;
       const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+      if (w == 0) { const uint4 q0 = reinterpret_cast<const uint4*>(k)[0], q1 = reinterpret_cast<const uint4*>(k)[1];
+        const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }      // scalar >= r: reported by the host wrapper, never summed silently
       const int d = window_digit_indep(k, (int)w, s.c);
       if (d == 0) continue;
       const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);

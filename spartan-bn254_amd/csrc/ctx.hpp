@@ -19,9 +19,12 @@ struct sbn_ctx {
   hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
   hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
   DevBuf zstage[2], out_rows, comb_partial;
+  int sc_waves = 2;           // streaming sumcheck rounds: 2 = software-pipelined loads, 2 waves per SIMD (default); 3 / 4 = the plain kernel at that occupancy (SBN_SC_WAVES)
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)
   void* pin = nullptr; size_t pin_cap = 0;   // pinned host staging for small D2H results
+  uint32_t* d_bad = nullptr;                 // device word: scalars >= r met by the kernels that read the caller's input (input_check_*)
+  uint32_t* h_bad = nullptr;                 // its pinned host copy
   uint32_t* mbox = nullptr; uint32_t mbox_seq = 0;   // coherent pinned mailbox of the single-launch sumcheck rounds (results + per-instance flags)
   std::vector<std::pair<void*, size_t>> pool; size_t pool_bytes = 0;   // cached table buffers (see pool_get)
   uint64_t last_job[4] = {0, 0, 0, 0};      // window bits, windows, (digit, point) slots, buckets of the most recent bucket job
@@ -96,6 +99,15 @@ static int ensure(sbn_ctx* c, DevBuf& b, size_t bytes) {
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) { b.p = nullptr; return fail(c, SBN_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); }
   b.cap = want;
+  return SBN_OK;
+}
+// Non-canonical input scalars (>= r): Scalar::from_bytes rejects them (scalar.rs:87-95) and the digit recoding assumes the top
+// window cannot carry out, so the kernels that read caller-provided scalars count them in c->d_bad.  An entry point clears the
+// counter before its first launch, copies it back with its result and turns a non-zero count into SBN_EINVAL.
+static int input_check_begin(sbn_ctx* c) { HIPCHK(c, hipMemsetAsync(c->d_bad, 0, 4, c->stream)); return SBN_OK; }
+static int input_check_fetch(sbn_ctx* c) { HIPCHK(c, hipMemcpyAsync(c->h_bad, c->d_bad, 4, hipMemcpyDeviceToHost, c->stream)); return SBN_OK; }   // enqueue before the final synchronisation
+static int input_check_end(sbn_ctx* c) {
+  if (*c->h_bad) return fail(c, SBN_EINVAL, "%u input scalars are not canonical (>= r; Scalar::from_bytes rejects them, scalar.rs:87-95)", *c->h_bad);
   return SBN_OK;
 }
 static int ensure_pin(sbn_ctx* c, size_t bytes) {

@@ -218,6 +218,53 @@ template <class M> __device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const
   Fe<M> r; fe_cond_sub_p<M>(r.v, t);
   return r;
 }
+// The same product with DEFERRED carry captures (fp_rows_gen.inc, generated by tools/gen_fe_mul.py): the 8 mads of a row issue
+// back to back, each carry-out into its own SGPR pair, and the captures follow the second row.  Same instruction count, different
+// order: no instruction depends on the one before it, so one wave keeps the multiplier busy by itself.
+#include "fp_rows_gen.inc"
+template <class M> __device__ __forceinline__ Fe<M> fe_mul_deferred(const Fe<M>& a, const Fe<M>& b) {
+  uint64_t A[8];
+  uint32_t C[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) C[j] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint32_t bi = b.v[i];
+    uint64_t S[7];
+    if (i == 0) SBN_ROW_AB0(A, a.v, bi); else SBN2_ROW_AB(A, S, a.v, bi);
+    const uint32_t m = (uint32_t)A[0] * M::NINV;
+    if (i == 0) SBN2_ROW_MP0(A, C, m, M) else SBN2_ROW_MP(A, C, S, m, M)
+    uint32_t lo = (uint32_t)A[1], hi = (uint32_t)(A[1] >> 32);
+    const uint32_t a0hi = (uint32_t)(A[0] >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc"
+        : "+v"(lo), "+v"(hi), "+v"(C[3]) : "v"(a0hi), "v"(C[2]) : "vcc");
+    A[0] = ((uint64_t)hi << 32) | lo;
+#pragma unroll
+    for (int k = 1; k < 7; k++) A[k] = A[k + 1];
+#pragma unroll
+    for (int j = 2; j < 8; j++) C[j] = C[j + 1];
+    C[8] = 0;
+  }
+  uint32_t lo[8], hi[8];
+#pragma unroll
+  for (int k = 0; k < 7; k++) { lo[k] = (uint32_t)A[k]; hi[k] = (uint32_t)(A[k] >> 32); }
+  uint32_t t[8];
+  t[0] = lo[0];
+  asm("v_add_co_u32 %0, vcc, %7, %14\n\tv_addc_co_u32 %1, vcc, %8, %15, vcc\n\t"
+      "v_addc_co_u32 %2, vcc, %9, %16, vcc\n\tv_addc_co_u32 %3, vcc, %10, %17, vcc\n\t"
+      "v_addc_co_u32 %4, vcc, %11, %18, vcc\n\tv_addc_co_u32 %5, vcc, %12, %19, vcc\n\t"
+      "v_addc_co_u32 %6, vcc, 0, %13, vcc\n\t"
+      "v_add_co_u32 %1, vcc, %1, %20\n\tv_addc_co_u32 %2, vcc, %2, %21, vcc\n\t"
+      "v_addc_co_u32 %3, vcc, %3, %22, vcc\n\tv_addc_co_u32 %4, vcc, %4, %23, vcc\n\t"
+      "v_addc_co_u32 %5, vcc, %5, %24, vcc\n\tv_addc_co_u32 %6, vcc, %6, %25, vcc"
+      : "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+      : "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(hi[4]), "v"(hi[5]), "v"(hi[6]),
+        "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(lo[4]), "v"(lo[5]), "v"(lo[6]),
+        "v"(C[2]), "v"(C[3]), "v"(C[4]), "v"(C[5]), "v"(C[6]), "v"(C[7])
+      : "vcc");
+  Fe<M> r; fe_cond_sub_p<M>(r.v, t);
+  return r;
+}
 template <class M> __device__ __forceinline__ Fe<M> fe_sqr(const Fe<M>& a) { return fe_mul<M>(a, a); }
 
 // canonical integer (8 limbs, < p) <-> Montgomery
@@ -244,6 +291,14 @@ template <class M> __device__ __noinline__ Fe<M> fe_inv(const Fe<M>& a) {
   return acc;
 }
 
+// value < modulus?  (8 little-endian limbs; what Scalar::from_bytes checks, scalar.rs:87-95)
+template <class M> __device__ __forceinline__ bool fe_is_canonical(const uint32_t k[8]) {
+  uint64_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)k[i] - modlimb<M>(i) - borrow; borrow = d >> 63; }
+  return borrow != 0;        // k - p borrowed  <=>  k < p
+}
+
 // 16-byte vector load/store of a field element (AoS, 32 B, 16 B aligned)
 template <class M> __device__ __forceinline__ Fe<M> fe_load(const void* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
@@ -255,6 +310,26 @@ template <class M> __device__ __forceinline__ void fe_store(void* p, const Fe<M>
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
   q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+// The same on a pointer KNOWN to be global memory.  Pointers that reach a kernel inside a by-value argument struct, or that are
+// loaded from memory (pointer tables), are generic to the compiler: it emits flat_load / flat_store, and a flat access counts on
+// both vmcnt and lgkmcnt and returns out of order, so every wait degenerates to `s_waitcnt vmcnt(0) lgkmcnt(0)` and no load can
+// stay in flight across a use (measured on the fused sumcheck round: the prefetch of the next table was drained by the very next
+// wait).  The explicit address-space-1 access types make the instruction itself global_load_dwordx4 / global_store_dwordx4.
+typedef uint32_t sbn_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) sbn_u32x4 sbn_g_u32x4;
+template <class M> __device__ __forceinline__ Fe<M> fe_gload(const void* p) {
+  const sbn_g_u32x4* q = (const sbn_g_u32x4*)p;
+  const sbn_u32x4 lo = q[0], hi = q[1];
+  Fe<M> r; r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w; r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+  return r;
+}
+template <class M> __device__ __forceinline__ void fe_gstore(void* p, const Fe<M>& a) {
+  sbn_g_u32x4* q = (sbn_g_u32x4*)p;
+  sbn_u32x4 lo, hi;
+  lo.x = a.v[0]; lo.y = a.v[1]; lo.z = a.v[2]; lo.w = a.v[3]; hi.x = a.v[4]; hi.y = a.v[5]; hi.z = a.v[6]; hi.w = a.v[7];
+  q[0] = lo; q[1] = hi;
 }
 
 }  // namespace sbn

@@ -172,13 +172,16 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
   if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
   BucketJob J; memset(&J, 0, sizeof J);
   J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1, 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
-  J.da.scalars = d_scal; J.da.n = n; J.da.estride = n;
+  J.da.scalars = d_scal; J.da.n = n; J.da.estride = n; J.da.bad = c->d_bad;
   int rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;
+  if ((rc = input_check_begin(c))) return rc;
   if ((rc = run_bucket_job(c, J))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, J.P * 128, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = input_check_fetch(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof) prof_drain(c);
+  if ((rc = input_check_end(c))) return rc;
   // sum_w 2^(c w) S_w: the 254-doubling serial chain, on the host
   const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
   sbn_host::Pt total = sbn_host::combine_windows(S, J.s.W, J.s.c);
@@ -272,7 +275,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     const size_t U = b->U; int rc;
     if ((rc = ensure(c, c->merged, L * (U + 1) * 32 + L))) return rc;
     uint32_t* m = (uint32_t*)c->merged.p; uint8_t* rowflags = (uint8_t*)c->merged.p + L * (U + 1) * 32;
-    if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, R, rowflags);
+    if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, c->d_bad);
     else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
     if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
@@ -291,7 +294,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     // fixed-base lookup: W mixed additions per scalar, no buckets (comb_kernels.cuh)
     const MsmShape s = make_shape(b->comb_c);
     DigitArgs da; memset(&da, 0, sizeof da);
-    da.scalars = dZ; da.blinds = dBl; da.n = ncol; da.R = R; da.L = L; da.tstride = npts;
+    da.scalars = dZ; da.blinds = dBl; da.n = ncol; da.R = R; da.L = L; da.tstride = npts; da.bad = c->d_bad;
     // few rows: spread a row over S blocks so that a lane's chain is ~4 mixed additions (latency-bound regime)
     unsigned S = 1; while ((size_t)L * S < 2048 && S < 64 && (size_t)S * 1024 < ncol * (size_t)s.W) S <<= 1;
     if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = (unsigned)v; }
@@ -322,7 +325,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   int rc; const uint32_t* tab;
   if ((rc = bases_window_table(c, b, J.s, &tab))) return rc;
   J.points = tab;
-  J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W;
+  J.da.scalars = dZ; J.da.blinds = dBl; J.da.n = ncol; J.da.R = R; J.da.L = L; J.da.tstride = npts; J.da.estride = ncol * (size_t)J.s.W; J.da.bad = c->d_bad;
   J.skip = skip_rows;
   if ((rc = run_bucket_job(c, J))) return rc;
   if (d_xy) LAUNCH(c, "k_xyzz_to_affine", k_xyzz_to_affine, (unsigned)((L + 63) / 64), 64, (const uint32_t*)c->wsum.p, (uint32_t*)nullptr, d_xy, d_inf, L);
@@ -333,13 +336,16 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
 static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
   if (L == 0) return SBN_OK;
   int rc;
+  if ((rc = input_check_begin(c))) return rc;
   if (L <= 16) {
     // a handful of rows: the per-row Fermat inversion is a ~0.3 ms single-lane chain on the device and ~15 us on a host core
     if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 128)))) return rc;
     if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, nullptr, nullptr))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, L * 128, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = input_check_fetch(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->prof) prof_drain(c);
+    if ((rc = input_check_end(c))) return rc;
     const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
     for (size_t i = 0; i < L; i++) { int inf = 0; sbn_host::to_affine_bytes(S[i], out_xy + 64 * i, &inf); if (out_inf) out_inf[i] = (uint8_t)inf; }
     return SBN_OK;
@@ -348,8 +354,10 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
   if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->pin, c->out_small.p, L * 65, hipMemcpyDeviceToHost, c->stream));
+  if ((rc = input_check_fetch(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->prof) prof_drain(c);
+  if ((rc = input_check_end(c))) return rc;
   memcpy(out_xy, c->pin, L * 64);
   if (out_inf) memcpy(out_inf, (uint8_t*)c->pin + L * 64, L);
   return SBN_OK;

@@ -56,14 +56,15 @@ __device__ __forceinline__ int window_digit_indep(const uint32_t* __restrict__ k
 }
 
 // Montgomery-form scalars -> canonical integers (only when the caller passes ark-ff's in-memory limbs)
-__global__ void __launch_bounds__(256) k_scalars_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+__global__ void __launch_bounds__(256) k_scalars_from_mont(const uint32_t* in, uint32_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr a = fe_load<FrP>(in + 8 * i);
   fe_store<FrP>(out + 8 * i, fe_from_mont(a));
 }
 // canonical affine points -> Montgomery coordinates
-__global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+// (also run in place: no __restrict__)
+__global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* in, uint32_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fq x = fe_load<FqP>(in + 16 * i), y = fe_load<FqP>(in + 16 * i + 8);
@@ -86,6 +87,7 @@ struct DigitArgs {
   size_t L;                  // ROWS: number of rows
   size_t tstride;            // ROWS: points per window slab of the table
   size_t estride;            // sorted-entry capacity per problem
+  uint32_t* bad;             // device counter of scalars >= r met while reading the caller's input (never null)
 };
 
 // signed digits of every scalar, stored once: dig[p*E + e].  Window bits never exceed 16 (LDS counter capacity), so a
@@ -106,6 +108,9 @@ __global__ void __launch_bounds__(256) k_digits_store(DigitArgs a, MsmShape s, d
     if (skip && skip[row] == 2) return;                  // all-zero row: k_sort_rows never reads its digits
     k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
   }
+  { uint32_t kk[8]; const uint4 k0 = reinterpret_cast<const uint4*>(k)[0], k1 = reinterpret_cast<const uint4*>(k)[1];
+    kk[0] = k0.x; kk[1] = k0.y; kk[2] = k0.z; kk[3] = k0.w; kk[4] = k1.x; kk[5] = k1.y; kk[6] = k1.z; kk[7] = k1.w;
+    if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }   // a value >= r would drop the top window's carry: reported, never summed silently
   uint32_t carry = 0;
   for (int w = 0; w < s.W; w++) {
     const int d = window_digit(k, w, s.c, carry);
@@ -568,15 +573,25 @@ __device__ __forceinline__ Fr merged_load(const uint32_t* __restrict__ Z, const 
 // extra column, the row's value goes there and every other merged scalar of the row is zero (only h keeps the blind).
 // flags[row] = 0: general row, 1: constant non-zero row, 2: all-zero row (hyrax.rs:245 padding; skipped by the later
 // stages when there are no blinds).  One block per row.
-__global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restrict__ Z, size_t R, uint8_t* __restrict__ flags) {
+// This is also the pass that sees every input scalar of the merge path: values >= r are counted in *bad (the Fr additions
+// that follow assume canonical operands; Scalar::from_bytes rejects them, scalar.rs:87-95).
+__global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t R, uint8_t* __restrict__ flags, uint32_t* __restrict__ bad) {
   const size_t row = blockIdx.x;
   const uint4* z = reinterpret_cast<const uint4*>(Z + 8 * row * R);
   const uint4 a0 = z[0], a1 = z[1];
-  int diff = 0;
+  int diff = 0, nbad = 0;
   for (size_t j = threadIdx.x; j < R; j += blockDim.x) {
     const uint4 b0 = z[2 * j], b1 = z[2 * j + 1];
     diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
+    const uint32_t kk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    nbad += fe_is_canonical<FrP>(kk) ? 0 : 1;
   }
+  if (blinds && threadIdx.x == 0) {
+    const uint4 b0 = reinterpret_cast<const uint4*>(blinds + 8 * row)[0], b1 = reinterpret_cast<const uint4*>(blinds + 8 * row)[1];
+    const uint32_t kk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    nbad += fe_is_canonical<FrP>(kk) ? 0 : 1;
+  }
+  if (nbad) atomicAdd(bad, (uint32_t)nbad);
   const int any = __syncthreads_or(diff != 0);
   if (threadIdx.x == 0) flags[row] = any ? 0 : (((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w) == 0) ? 2 : 1);
 }
@@ -656,6 +671,32 @@ __global__ void __launch_bounds__(64) k_arith_points(const uint32_t* __restrict_
     if ((k >> b) & 1ull) acc = xyzz_add(acc, D);
   }
   xyzz_store(out_xyzz + 32 * i, xyzz_add(acc, P0));
+}
+// Synthetic benchmark scalars: scalar t = the four SplitMix64 outputs of counters 4(first+t)+1 .. +4 as
+// little-endian u64 limbs, top limb cut to 62 bits, minus r when >= r (a 254-bit value is < 2r) -> canonical, full width.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(256) k_scalars_synthetic(unsigned long long seed, unsigned long long first, size_t n, uint32_t* __restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  uint32_t k[8];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    unsigned long long z = splitmix64(seed, 4ull * (first + t) + (unsigned long long)j + 1ull);
+    if (j == 3) z &= (1ull << 62) - 1ull;
+    k[2 * j] = (uint32_t)z; k[2 * j + 1] = (uint32_t)(z >> 32);
+  }
+  if (!fe_is_canonical<FrP>(k)) {
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)k[i] - modlimb<FrP>(i) - borrow; k[i] = (uint32_t)d; borrow = d >> 63; }
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + 8 * t);
+  o[0] = make_uint4(k[0], k[1], k[2], k[3]); o[1] = make_uint4(k[4], k[5], k[6], k[7]);
 }
 __global__ void __launch_bounds__(256) k_points_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

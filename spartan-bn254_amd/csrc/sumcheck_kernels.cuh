@@ -92,15 +92,15 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     if (KIND == KIND_QUAD) {
-      Fr zl = fe_load<FrP>(a.t[0] + 8 * i), zh = fe_load<FrP>(a.t[0] + 8 * (i + half));
-      Fr al = fe_load<FrP>(a.t[1] + 8 * i), ah = fe_load<FrP>(a.t[1] + 8 * (i + half));
+      Fr zl = fe_gload<FrP>(a.t[0] + 8 * i), zh = fe_gload<FrP>(a.t[0] + 8 * (i + half));
+      Fr al = fe_gload<FrP>(a.t[1] + 8 * i), ah = fe_gload<FrP>(a.t[1] + 8 * (i + half));
       e0 = fe_add(e0, fe_mul(zl, al));
       Fr z2 = fe_sub(fe_dbl(zh), zl), a2 = fe_sub(fe_dbl(ah), al);
       e2 = fe_add(e2, fe_mul(z2, a2));
     } else if (KIND == KIND_CUBIC) {
-      Fr al = fe_load<FrP>(a.t[0] + 8 * i), ah = fe_load<FrP>(a.t[0] + 8 * (i + half));
-      Fr bl = fe_load<FrP>(a.t[1] + 8 * i), bh = fe_load<FrP>(a.t[1] + 8 * (i + half));
-      Fr cl = fe_load<FrP>(a.t[2] + 8 * i), ch = fe_load<FrP>(a.t[2] + 8 * (i + half));
+      Fr al = fe_gload<FrP>(a.t[0] + 8 * i), ah = fe_gload<FrP>(a.t[0] + 8 * (i + half));
+      Fr bl = fe_gload<FrP>(a.t[1] + 8 * i), bh = fe_gload<FrP>(a.t[1] + 8 * (i + half));
+      Fr cl = fe_gload<FrP>(a.t[2] + 8 * i), ch = fe_gload<FrP>(a.t[2] + 8 * (i + half));
       e0 = fe_add(e0, fe_mul(fe_mul(al, bl), cl));
       Fr da = fe_sub(ah, al), db = fe_sub(bh, bl), dc = fe_sub(ch, cl);
       Fr a2 = fe_add(ah, da), b2 = fe_add(bh, db), c2 = fe_add(ch, dc);        // 2*hi - lo
@@ -108,10 +108,10 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
       Fr a3 = fe_add(a2, da), b3 = fe_add(b2, db), c3 = fe_add(c2, dc);        // p(2) + hi - lo
       e3 = fe_add(e3, fe_mul(fe_mul(a3, b3), c3));
     } else {
-      Fr tl = fe_load<FrP>(a.t[0] + 8 * i), th = fe_load<FrP>(a.t[0] + 8 * (i + half));
-      Fr al = fe_load<FrP>(a.t[1] + 8 * i), ah = fe_load<FrP>(a.t[1] + 8 * (i + half));
-      Fr bl = fe_load<FrP>(a.t[2] + 8 * i), bh = fe_load<FrP>(a.t[2] + 8 * (i + half));
-      Fr cl = fe_load<FrP>(a.t[3] + 8 * i), ch = fe_load<FrP>(a.t[3] + 8 * (i + half));
+      Fr tl = fe_gload<FrP>(a.t[0] + 8 * i), th = fe_gload<FrP>(a.t[0] + 8 * (i + half));
+      Fr al = fe_gload<FrP>(a.t[1] + 8 * i), ah = fe_gload<FrP>(a.t[1] + 8 * (i + half));
+      Fr bl = fe_gload<FrP>(a.t[2] + 8 * i), bh = fe_gload<FrP>(a.t[2] + 8 * (i + half));
+      Fr cl = fe_gload<FrP>(a.t[3] + 8 * i), ch = fe_gload<FrP>(a.t[3] + 8 * (i + half));
       e0 = fe_add(e0, fe_mul(tl, fe_sub(fe_mul(al, bl), cl)));
       Fr dt = fe_sub(th, tl), da = fe_sub(ah, al), db = fe_sub(bh, bl), dc = fe_sub(ch, cl);
       Fr t2 = fe_add(th, dt), a2 = fe_add(ah, da), b2 = fe_add(bh, db), c2 = fe_add(ch, dc);
@@ -143,14 +143,37 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
 // values, in one pass: per table 4 elements are read (quarter q of the old length apart), the two bound values are
 // written to the table's second buffer and feed the next round's evaluation points directly.  One pass per round
 // instead of two: the separate eval pass (a full re-read of the bound tables) disappears.
-// dst[j] == nullptr means another instance writes that (shared) table; values are still computed for the sums.
+//   dst[j] == nullptr : another instance writes that (shared) table; values are still computed for the sums.
+//   pre[j] != 0       : src[j] is ALREADY bound (the "par" instances of prove_cubic_batched share one C table,
+//                       sumcheck.rs:201-235: it is bound once by k_bind_oop ahead of this launch and every instance reads the two
+//                       bound values instead of re-reading four and re-binding them: -2 of 12 products and -2 of 12 loads each).
+// The tables of an instance are taken one after another and only the running products at the points 0, 2, 3 stay live, so the
+// kernel fits 4 waves per SIMD; the challenge arrives in Montgomery form (one host product instead of one per thread), and the
+// grid is sized for a few block rounds so that the wave/LDS reduction at the end is amortised over many indices per thread.
 struct ScFusedArgs {
   const uint32_t* src[4];
   uint32_t* dst[4];
+  uint32_t pre[4];
 };
 struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
-template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rc /* canonical */, uint32_t* __restrict__ partial,
+
+
+// one table at index i: bound values lo = Z'[i], hi = Z'[i + q]
+struct ScPair { Fr lo, hi; };
+__device__ __forceinline__ ScPair sc_bound_pair(const uint32_t* __restrict__ z, uint32_t* __restrict__ dst, uint32_t pre, size_t i, size_t q, const Fr& r) {
+  ScPair o;
+  if (pre) { o.lo = fe_gload<FrP>(z + 8 * i); o.hi = fe_gload<FrP>(z + 8 * (i + q)); return o; }
+  const Fr z0 = fe_gload<FrP>(z + 8 * i), z2 = fe_gload<FrP>(z + 8 * (i + 2 * q));
+  const Fr z1 = fe_gload<FrP>(z + 8 * (i + q)), z3 = fe_gload<FrP>(z + 8 * (i + 3 * q));
+  o.lo = fe_add(z0, fe_mul(r, fe_sub(z2, z0)));
+  o.hi = fe_add(z1, fe_mul(r, fe_sub(z3, z1)));
+  if (dst) { fe_gstore<FrP>(dst + 8 * i, o.lo); fe_gstore<FrP>(dst + 8 * (i + q), o.hi); }
+  return o;
+}
+
+// WPS = waves per SIMD the register allocation is held to (4 -> 128 VGPRs with a few spilled dwords; 3 -> no spills)
+template <int KIND, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial,
                                                       uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
   ScFusedArgs a;
   if (args) a = args[blockIdx.y];
@@ -158,36 +181,32 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restr
 #pragma unroll
     for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
   }
-  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rc.v[k];
-  r = fe_to_mont(r);
-  constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
+  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rmont.v[k];
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-    Fr lo[NT], hi[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-      const uint32_t* z = a.src[j];
-      const Fr z0 = fe_load<FrP>(z + 8 * i), z1 = fe_load<FrP>(z + 8 * (i + q)), z2 = fe_load<FrP>(z + 8 * (i + 2 * q)), z3 = fe_load<FrP>(z + 8 * (i + 3 * q));
-      lo[j] = fe_add(z0, fe_mul(r, fe_sub(z2, z0)));
-      hi[j] = fe_add(z1, fe_mul(r, fe_sub(z3, z1)));
-      if (a.dst[j]) { fe_store<FrP>(a.dst[j] + 8 * i, lo[j]); fe_store<FrP>(a.dst[j] + 8 * (i + q), hi[j]); }
-    }
+#define SC_TAB(j) sc_bound_pair(a.src[j], a.dst[j], a.pre[j], i, q, r)
     if (KIND == KIND_QUAD) {
-      e0 = fe_add(e0, fe_mul(lo[0], lo[1]));
-      e2 = fe_add(e2, fe_mul(fe_sub(fe_dbl(hi[0]), lo[0]), fe_sub(fe_dbl(hi[1]), lo[1])));
+      const ScPair z = SC_TAB(0);
+      const Fr z2 = fe_sub(fe_dbl(z.hi), z.lo);
+      const ScPair w = SC_TAB(1);
+      e0 = fe_add(e0, fe_mul(z.lo, w.lo));
+      e2 = fe_add(e2, fe_mul(z2, fe_sub(fe_dbl(w.hi), w.lo)));
     } else if (KIND == KIND_CUBIC) {
-      e0 = fe_add(e0, fe_mul(fe_mul(lo[0], lo[1]), lo[2]));
-      Fr da = fe_sub(hi[0], lo[0]), db = fe_sub(hi[1], lo[1]), dc = fe_sub(hi[2], lo[2]);
-      Fr a2 = fe_add(hi[0], da), b2 = fe_add(hi[1], db), c2 = fe_add(hi[2], dc);
-      e2 = fe_add(e2, fe_mul(fe_mul(a2, b2), c2));
-      e3 = fe_add(e3, fe_mul(fe_mul(fe_add(a2, da), fe_add(b2, db)), fe_add(c2, dc)));
+      Fr p0, p2, p3;
+      { const ScPair t = SC_TAB(0); const Fr d = fe_sub(t.hi, t.lo); p0 = t.lo; p2 = fe_add(t.hi, d); p3 = fe_add(p2, d); }   // p(2) = 2 hi - lo, p(3) = p(2) + hi - lo
+      { const ScPair t = SC_TAB(1); const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+      { const ScPair t = SC_TAB(2); const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+      e0 = fe_add(e0, p0); e2 = fe_add(e2, p2); e3 = fe_add(e3, p3);
     } else {
-      e0 = fe_add(e0, fe_mul(lo[0], fe_sub(fe_mul(lo[1], lo[2]), lo[3])));
-      Fr dt = fe_sub(hi[0], lo[0]), da = fe_sub(hi[1], lo[1]), db = fe_sub(hi[2], lo[2]), dc = fe_sub(hi[3], lo[3]);
-      Fr t2 = fe_add(hi[0], dt), a2 = fe_add(hi[1], da), b2 = fe_add(hi[2], db), c2 = fe_add(hi[3], dc);
-      e2 = fe_add(e2, fe_mul(t2, fe_sub(fe_mul(a2, b2), c2)));
-      e3 = fe_add(e3, fe_mul(fe_add(t2, dt), fe_sub(fe_mul(fe_add(a2, da), fe_add(b2, db)), fe_add(c2, dc))));
+      // tau * (Az * Bz - Cz): tables 1, 2 (product), 3 (subtracted), then 0 (tau)
+      Fr p0, p2, p3;
+      { const ScPair t = SC_TAB(1); const Fr d = fe_sub(t.hi, t.lo); p0 = t.lo; p2 = fe_add(t.hi, d); p3 = fe_add(p2, d); }
+      { const ScPair t = SC_TAB(2); const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+      { const ScPair t = SC_TAB(3); const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_sub(p0, t.lo); p2 = fe_sub(p2, v); p3 = fe_sub(p3, fe_add(v, d)); }
+      { const ScPair t = SC_TAB(0); const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+      e0 = fe_add(e0, p0); e2 = fe_add(e2, p2); e3 = fe_add(e3, p3);
     }
+#undef SC_TAB
   }
   __shared__ uint32_t sm[4][3][8];
   e0 = wave_sum_fr(e0); e2 = wave_sum_fr(e2);
@@ -207,6 +226,130 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval(const ScFusedArgs* __restr
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
+// The streaming form of the fused round (tables of 2^16 entries and more).  Measured on MI355X: the plain form above keeps too
+// few bytes in flight — a wave issues the four loads of a table, waits, computes ~5 products, and only then issues the next
+// table's loads, so with 3-4 waves per SIMD about 20 KB per CU are in flight on average and the round runs at ~2.9 TB/s with
+// the multiplier 60 % busy (neither HBM nor the VALU saturated).  Here the NEXT table's elements are loaded into a second
+// register set before the current table's arithmetic starts (software pipeline over the flattened (index, table) sequence):
+// every wave has 8 KB in flight all the time.  The price is registers (2 waves per SIMD), which a VALU-dense loop without
+// exposed load latency tolerates (tools/micro/ecbench.hip: 94 % of the mixed-addition ceiling at 2 waves per SIMD).
+// PRE (which tables arrive pre-bound) is a compile-time mask: with run-time branches around the loads the compiler sinks every
+// "prefetch" back down to its use (seen in the ISA), which is exactly the serial load -> wait -> compute chain this form removes.
+// A table that is not pre-bound always has its writer here (the host pre-binds every shared table on this path).
+struct ScQuad { Fr z0, z1, z2, z3; };     // the four elements of one table at index i (pre-bound table: z0 = lo, z1 = hi)
+template <bool PRE> __device__ __forceinline__ ScQuad sc_quad_load(const uint32_t* __restrict__ z, size_t i, size_t q) {
+  ScQuad o;
+  o.z0 = fe_gload<FrP>(z + 8 * i); o.z1 = fe_gload<FrP>(z + 8 * (i + q));
+  if (!PRE) { o.z2 = fe_gload<FrP>(z + 8 * (i + 2 * q)); o.z3 = fe_gload<FrP>(z + 8 * (i + 3 * q)); }
+  return o;
+}
+template <bool PRE> __device__ __forceinline__ ScPair sc_quad_bind(const ScQuad& z, uint32_t* __restrict__ dst, size_t i, size_t q, const Fr& r) {
+  ScPair o;
+  if (PRE) { o.lo = z.z0; o.hi = z.z1; return o; }
+  o.lo = fe_add(z.z0, fe_mul(r, fe_sub(z.z2, z.z0)));
+  o.hi = fe_add(z.z1, fe_mul(r, fe_sub(z.z3, z.z1)));
+  fe_gstore<FrP>(dst + 8 * i, o.lo); fe_gstore<FrP>(dst + 8 * (i + q), o.hi);
+  return o;
+}
+// table order: cubic 0,1,2 — r1cs 1,2,3,0 (tau last: tau * (Az*Bz - Cz)) — quad 0,1.  PREMASK bit t = the t-th table IN THAT ORDER is pre-bound.
+template <int KIND, int PREMASK>
+__device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const Fr& r, Fr& e0, Fr& e2, Fr& e3) {
+  constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
+  constexpr int T0 = KIND == KIND_R1CS ? 1 : 0, T1 = KIND == KIND_R1CS ? 2 : 1, T2 = KIND == KIND_R1CS ? 3 : 2, T3 = 0;
+  constexpr bool P0 = (PREMASK & 1) != 0, P1 = (PREMASK & 2) != 0, P2 = (PREMASK & 4) != 0, P3 = (PREMASK & 8) != 0;
+  const uint32_t* s0 = a.src[T0]; const uint32_t* s1 = a.src[T1];
+  const uint32_t* s2 = a.src[NT > 2 ? T2 : T0]; const uint32_t* s3 = a.src[NT > 3 ? T3 : T0];
+  uint32_t* d0 = a.dst[T0]; uint32_t* d1 = a.dst[T1];
+  uint32_t* d2 = a.dst[NT > 2 ? T2 : T0]; uint32_t* d3 = a.dst[NT > 3 ? T3 : T0];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q) return;
+  ScQuad zn = sc_quad_load<P0>(s0, i, q);
+  // the scheduler otherwise moves every prefetch down to its first use (fewer live registers, and the serial chain back):
+  // nothing crosses SC_PIN, so the loads stay issued ahead of the arithmetic of the stage they overlap
+#define SC_PIN() __builtin_amdgcn_sched_barrier(0)
+  for (;;) {
+    const size_t inext = i + stride;
+    const size_t ipre = inext < q ? inext : i;          // the last iteration re-loads its own first table (harmless) instead of branching
+    Fr p0, p2, p3;
+    {
+      const ScQuad z = zn; zn = sc_quad_load<P1>(s1, i, q); SC_PIN();
+      const ScPair t = sc_quad_bind<P0>(z, d0, i, q, r);
+      if (KIND == KIND_QUAD) { p0 = t.lo; p2 = fe_sub(fe_dbl(t.hi), t.lo); }
+      else { const Fr d = fe_sub(t.hi, t.lo); p0 = t.lo; p2 = fe_add(t.hi, d); p3 = fe_add(p2, d); }      // p(2) = 2 hi - lo, p(3) = p(2) + hi - lo
+    }
+    {
+      const ScQuad z = zn;
+      if (NT > 2) zn = sc_quad_load<P2>(s2, i, q); else zn = sc_quad_load<P0>(s0, ipre, q);
+      SC_PIN();
+      const ScPair t = sc_quad_bind<P1>(z, d1, i, q, r);
+      if (KIND == KIND_QUAD) { p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, fe_sub(fe_dbl(t.hi), t.lo)); }
+      else { const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d); p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+    }
+    if (NT > 2) {
+      const ScQuad z = zn;
+      if (NT > 3) zn = sc_quad_load<P3>(s3, i, q); else zn = sc_quad_load<P0>(s0, ipre, q);
+      SC_PIN();
+      const ScPair t = sc_quad_bind<P2>(z, d2, i, q, r);
+      const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d);
+      if (KIND == KIND_CUBIC) { p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d)); }
+      else { p0 = fe_sub(p0, t.lo); p2 = fe_sub(p2, v); p3 = fe_sub(p3, fe_add(v, d)); }
+    }
+    if (NT > 3) {
+      const ScQuad z = zn;
+      zn = sc_quad_load<P0>(s0, ipre, q); SC_PIN();
+      const ScPair t = sc_quad_bind<P3>(z, d3, i, q, r);
+      const Fr d = fe_sub(t.hi, t.lo), v = fe_add(t.hi, d);
+      p0 = fe_mul(p0, t.lo); p2 = fe_mul(p2, v); p3 = fe_mul(p3, fe_add(v, d));
+    }
+    e0 = fe_add(e0, p0); e2 = fe_add(e2, p2);
+    if (KIND != KIND_QUAD) e3 = fe_add(e3, p3);
+    if (inext >= q) break;
+    i = inext;
+  }
+#undef SC_PIN
+}
+// host side: the masks this kernel is built for (anything else takes the plain kernel)
+__host__ __device__ inline bool sc_pf_mask_supported(int kind, unsigned mask) { return mask == 0 || (kind == KIND_CUBIC && mask == 4u); }
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial) {
+  ScFusedArgs a;
+  if (args) a = args[blockIdx.y];
+  else {
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
+  }
+  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rmont.v[k];
+  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+  if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3);   // "par" instance: the shared C arrives bound
+  else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3);
+  __shared__ uint32_t sm[4][3][8];
+  e0 = wave_sum_fr(e0); e2 = wave_sum_fr(e2);
+  if (KIND != KIND_QUAD) e3 = wave_sum_fr(e3);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < 8; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
+    uint32_t* o = partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x);
+    for (int k = 0; k < 8; k++) o[k] = s.v[k];
+  }
+}
+
+// out-of-place bind of the top variable of ONE table: dst[i] = Z[i] + r (Z[i + half] - Z[i]), i < half.  Runs ahead of a fused
+// round for a table that several instances of the round share (see ScFusedArgs::pre).
+__global__ void __launch_bounds__(256) k_bind_oop(const uint32_t* __restrict__ Z, uint32_t* __restrict__ dst, size_t half, ScScalar rmont) {
+  Fr r; for (int k = 0; k < 8; k++) r.v[k] = rmont.v[k];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    const Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
+    fe_store<FrP>(dst + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
+  }
+}
+
 // out[inst][3] canonical; one 64-lane block per instance folds `nblk` partial triples
 __global__ void __launch_bounds__(64) k_sc_finish(const uint32_t* __restrict__ partial, int nblk, uint32_t* __restrict__ out) {
   const int inst = blockIdx.x, lane = threadIdx.x;
@@ -223,8 +366,8 @@ __global__ void __launch_bounds__(256) k_bind_top(uint32_t* const* __restrict__ 
   uint32_t* Z = tabs[blockIdx.y];
   const Fr r = fe_load<FrP>(rm);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
-    fe_store<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
+    Fr lo = fe_gload<FrP>(Z + 8 * i), hi = fe_gload<FrP>(Z + 8 * (i + half));
+    fe_gstore<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
   }
 }
 
@@ -238,11 +381,12 @@ __global__ void __launch_bounds__(256) k_bind_top_packed(BindPack pack, size_t h
   Fr r; for (int k = 0; k < 8; k++) r.v[k] = rc.v[k];
   r = fe_to_mont(r);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
-    fe_store<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
+    Fr lo = fe_gload<FrP>(Z + 8 * i), hi = fe_gload<FrP>(Z + 8 * (i + half));
+    fe_gstore<FrP>(Z + 8 * i, fe_add(lo, fe_mul(r, fe_sub(hi, lo))));
   }
 }
-__global__ void __launch_bounds__(256) k_fr_to_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
+// (also run in place: no __restrict__)
+__global__ void __launch_bounds__(256) k_fr_to_mont(const uint32_t* in, uint32_t* out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     fe_store<FrP>(out + 8 * i, fe_to_mont(fe_load<FrP>(in + 8 * i)));
 }

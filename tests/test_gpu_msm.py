@@ -394,11 +394,39 @@ def test_msm_large_skew(ctx, ol, pr):
         b.free()
 
 
-def _dev_scalars(torch, n, seed):
-    g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    x = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int32, device="cuda", generator=g)
-    x[:, 7] &= 0x0fffffff           # < 2^252 < r : canonical
+def _dev_scalars(torch, n, seed, ctx=None):
+    """n scalars uniform in Fr, FULL width (bits 252 / 253 set on ~3/4 of them), generated on the device by sbn_scalars_synthetic
+    (SplitMix64 reduced mod r) as an (n, 8) int32 tensor"""
+    x = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+    _CTX[0].scalars_synthetic(0x5BA27A2B4E254 + seed, 0, n, x.data_ptr())
     return x
+
+
+_CTX = [None]
+
+
+@pytest.fixture(autouse=True)
+def _remember_ctx(ctx):
+    _CTX[0] = ctx
+
+
+def _add_mod_r(torch, pr, k1, k2):
+    """(k1 + k2) mod r on (n, 8) int32 limb tensors of canonical values"""
+    n = k1.shape[0]
+    ks = (k1.to(torch.int64) & 0xffffffff) + (k2.to(torch.int64) & 0xffffffff)
+    carry = torch.zeros(n, dtype=torch.int64, device=k1.device)
+    for j in range(8):
+        v = ks[:, j] + carry; ks[:, j] = v & 0xffffffff; carry = v >> 32
+    rl = [(pr.R >> (32 * j)) & 0xffffffff for j in range(8)]
+    ge = torch.ones(n, dtype=torch.bool, device=k1.device); decided = torch.zeros(n, dtype=torch.bool, device=k1.device)
+    for j in range(7, -1, -1):
+        gt = (ks[:, j] > rl[j]) & ~decided; lt = (ks[:, j] < rl[j]) & ~decided
+        ge = torch.where(lt, torch.zeros_like(ge), ge); decided |= gt | lt
+    borrow = torch.zeros(n, dtype=torch.int64, device=k1.device)
+    for j in range(8):
+        v = ks[:, j] - torch.where(ge, torch.full_like(borrow, rl[j]), torch.zeros_like(borrow)) - borrow
+        borrow = (v < 0).to(torch.int64); ks[:, j] = v & 0xffffffff
+    return ks.to(torch.int32).contiguous()          # values >= 2^31 wrap to the same 32 raw bits
 
 
 def test_full_size_properties_2p20(ctx, ol, pr):
@@ -416,12 +444,9 @@ def test_full_size_properties_2p20(ctx, ol, pr):
         k1b = k1.cpu().numpy().tobytes(); k2b = k2.cpu().numpy().tobytes()
         assert o1 == expect_from_dlogs(ol, pr, k1b, dl)
         assert o2 == expect_from_dlogs(ol, pr, k2b, dl)
-        # linearity: MSM(k1 + k2) == MSM(k1) + MSM(k2)   (sum of two < 2^252 values stays canonical)
-        ks = (k1.to(torch.int64) + k2.to(torch.int64))
-        carry = torch.zeros(n, dtype=torch.int64, device="cuda")
-        for j in range(8):
-            v = ks[:, j] + carry; ks[:, j] = v & 0xffffffff; carry = v >> 32
-        ks32 = ks.to(torch.int32).contiguous()          # values >= 2^31 wrap to the same 32 raw bits
+        # linearity: MSM(k1 + k2 mod r) == MSM(k1) + MSM(k2)
+        ks32 = _add_mod_r(torch, pr, k1, k2)
+        assert (np.frombuffer(k1b, dtype=np.uint32).reshape(n, 8)[:, 7] >> 28).max() >= 2          # full width: bits 252/253 are in use
         torch.cuda.synchronize()                         # the library runs on its own stream, not torch's
         os_, _ = ctx.msm_bases_dev(b, ks32.data_ptr(), n)
         assert os_ == ol.g1_add(o1, o2)
@@ -450,7 +475,7 @@ def _dot_arith(pr, scalars, first, n):
     return ((S0 * sum_k + DSTEP * (sum_ik + first * sum_k)) % pr.R).to_bytes(32, "little")
 
 
-@pytest.mark.parametrize("logn", [22, 23])
+@pytest.mark.parametrize("logn", [22, 23, 24])
 def test_large_msm_dlog_identity(ctx, ol, pr, logn):
     """upper part of the BASELINE size range (2^23 = one GPU's share of config 4, 2^26 over 8 GPUs): window bits at the
     16-bit cap, many chunks per window, long bucket chains; checked exactly through the discrete-log identity"""
@@ -475,10 +500,11 @@ def test_hyrax_derefs_shape_properties(ctx, ol, pr):
     L, R = 4096, 8192
     bases, gxy = ctx.gens_new(R, b"gens_r1cs_eval")
     try:
-        Z = _dev_scalars(torch, L * R, 33)
+        Z = _dev_scalars(torch, L * R, 33)          # uniform in Fr, full width (254-bit eq-table values)
         Z[3072 * R:] = 0
         Z[5 * R:6 * R] = Z[5 * R]                 # one constant row (repeated mem[0], sparse_mlpoly_full.rs:89-101)
         torch.cuda.synchronize()
+        assert int(((Z[:3072 * R, 7].to(torch.int64) & 0xffffffff) >> 28).max()) >= 2
         out, infs = ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, R)
         assert all(infs[i] == 1 for i in range(3072, 4096)) and out[64 * 3072:] == bytes(64 * 1024)
         assert not any(infs[:3072])
@@ -597,3 +623,138 @@ def test_fuzz_lookup_table_commits(ctx, ol, pr):
             assert all((infs[i] == 1) == (want[64 * i:64 * i + 64] == bytes(64)) for i in range(L))
         finally:
             b.free()
+
+
+# ---- round 2 ---------------------------------------------------------------------------------------------------------
+def test_scalars_synthetic_matches_host_twin(ctx, pr):
+    """sbn_scalars_synthetic (device) == bench.splitmix_scalars (numpy) == the definition in SURVEY 8d config 2; canonical, full width"""
+    import torch
+    import bench
+    n, first, seed = 5000, 12345, 0x5BA27A2B4E254
+    x = torch.empty(32 * n, dtype=torch.uint8, device="cuda")
+    ctx.scalars_synthetic(seed, first, n, x.data_ptr())
+    got = x.cpu().numpy().tobytes()
+    assert got == bench.splitmix_scalars(n, seed, first)
+    M64 = (1 << 64) - 1
+
+    def sm(idx):
+        z = (seed + idx * 0x9E3779B97F4A7C15) & M64
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+    for t in (0, 1, 4999):
+        limbs = [sm(4 * (first + t) + j + 1) for j in range(4)]
+        limbs[3] &= (1 << 62) - 1
+        v = sum(l << (64 * j) for j, l in enumerate(limbs))
+        assert int.from_bytes(got[32 * t:32 * t + 32], "little") == (v - pr.R if v >= pr.R else v)
+    vals = [int.from_bytes(got[32 * t:32 * t + 32], "little") for t in range(n)]
+    assert max(vals) < pr.R and max(vals) >> 253 == 1 and sum(1 for v in vals if v >> 252) > n // 2
+
+
+def test_noncanonical_scalars_rejected(ctx, ol, pr, sbn):
+    """a scalar >= r (Scalar::from_bytes returns None for it, scalar.rs:87-95) must come back as an error from every entry point
+    that reads caller scalars — never as a wrong point with SBN_OK — and must leave the context usable"""
+    R = 64
+    gx, _ = ol.gens_new(R, b"gens_r1cs_eval")                       # duplicates: the merge path
+    gd, _ = ol.gens_new(R, b"distinct-set")                         # no duplicates: digits straight from the input
+    good = rand_scalars(3 * R, 7)
+    for badval in (pr.R, pr.R + 5, (1 << 256) - 1):
+        bad = bytearray(good); bad[32 * (R + 3):32 * (R + 4)] = badval.to_bytes(32, "little"); bad = bytes(bad)
+        pts = gd[:64 * R]
+        with pytest.raises(sbn.SbnError, match="canonical"):
+            ctx.msm(bad[:32 * 2 * R], (pts * 2))
+        for gens in (gx, gd):
+            b = ctx.bases_upload(gens[:64 * R], gens[64 * R:])
+            try:
+                with pytest.raises(sbn.SbnError, match="canonical"):
+                    ctx.commit_rows(b, bad, None, 3, R)
+                with pytest.raises(sbn.SbnError, match="canonical"):                       # a bad blind
+                    ctx.commit_rows(b, good, bad[32 * R:32 * (R + 3)][:64] + badval.to_bytes(32, "little"), 3, R)
+                ctx.bases_precompute(b, 8 << 20)                                             # lookup path
+                with pytest.raises(sbn.SbnError, match="canonical"):
+                    ctx.commit_rows(b, bad, None, 3, R)
+                assert ctx.commit_rows(b, good, None, 3, R)[0] == ol.commit_rows(good, None, 3, R, gens[:64 * R], gens[64 * R:], 4)
+            finally:
+                b.free()
+    # r - 1 is canonical and must work (top window full)
+    top = (pr.R - 1).to_bytes(32, "little") * 4
+    pts4 = gd[:64 * 4]
+    assert ctx.msm(top, pts4)[0] == ol.msm_naive(top, pts4)
+
+
+@pytest.mark.parametrize("variant", ["plain", "mont", "blinds", "dedupe", "lookup"])
+def test_commit_rows_chunked_forced(ctx, ol, pr, sbn, variant, monkeypatch):
+    """the chunked host path of sbn_commit_rows (two staging buffers, copy stream, copied / consumed events), forced onto a small
+    matrix: 7 chunks of 3 rows + a ragged last one.  Must equal the device-resident path and the oracle in every launch branch."""
+    L, R = 23, 96
+    label = b"gens_r1cs_eval" if variant in ("dedupe", "lookup") else b"chunk-distinct"
+    gx, _ = ol.gens_new(R, label)
+    Z = rand_scalars(L * R, 900)
+    Z = Z[:32 * R * 4] + bytes(32 * R) + Z[32 * R * 5:]                   # one zero row
+    bl = rand_scalars(L, 901) if variant in ("blinds", "lookup") else None
+    want = ol.commit_rows(Z, bl, L, R, gx[:64 * R], gx[64 * R:], 4)
+    flags = 0; Zin, blin = Z, bl
+    if variant == "mont":
+        rr = ((1 << 256) % pr.R).to_bytes(32, "little")
+        Zin = b"".join(ol.fe_op("mul", 1, Z[32 * i:32 * i + 32], rr) for i in range(L * R)); flags = sbn.SBN_SCALARS_MONT
+    b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+    try:
+        if variant == "lookup":
+            ctx.bases_precompute(b, 16 << 20)
+        monkeypatch.setenv("SBN_COMMIT_CHUNK_BYTES", str(3 * R * 32))
+        out_c, inf_c = ctx.commit_rows(b, Zin, blin, L, R, flags)
+        monkeypatch.delenv("SBN_COMMIT_CHUNK_BYTES")
+        out_1, inf_1 = ctx.commit_rows(b, Zin, blin, L, R, flags)          # one piece
+        d = ctx.dev_alloc(len(Zin)); ctx.dev_upload(d, Zin)
+        db = 0
+        if blin:
+            db = ctx.dev_alloc(len(blin)); ctx.dev_upload(db, blin)
+        out_d, inf_d = ctx.commit_rows_dev(b, d, db, L, R, flags)
+        ctx.dev_free(d)
+        if db:
+            ctx.dev_free(db)
+        assert out_c == want and out_1 == want and out_d == want
+        assert inf_c == inf_1 == inf_d
+        if not bl:
+            assert inf_c[4] == 1
+    finally:
+        b.free()
+
+
+def test_zero_size_calls_leave_no_error(ctx, ol, sbn):
+    """L = 0 / n = 0 with the Montgomery flag and blinds used to launch zero-size grids (a sticky HIP error for the next call)"""
+    R = 8
+    gx, _ = ol.gens_new(R, b"zs")
+    b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+    try:
+        d = ctx.dev_alloc(64)
+        assert ctx.commit_rows_dev(b, d, d, 0, R, sbn.SBN_SCALARS_MONT)[0] == b""
+        out, inf = ctx.msm_bases_dev(b, d, 0, sbn.SBN_SCALARS_MONT)
+        assert inf and out == bytes(64)
+        Z = rand_scalars(R, 1)
+        assert ctx.commit_rows(b, Z, None, 1, R)[0] == ol.commit_rows(Z, None, 1, R, gx[:64 * R], gx[64 * R:], 1)
+        ctx.dev_free(d)
+    finally:
+        b.free()
+
+
+@pytest.mark.parametrize("L,R,rows", [(2048, 2048, (0, 1, 777, 2047)), (8192, 8192, (0, 4095, 8191))])
+def test_encode_time_commitment_shapes(ctx, ol, L, R, rows):
+    """the encode-time commitments of SparseMatPolyCommitment (sparse_mlpoly_full.rs:183-184): comb_mem is 2048 x 2048,
+    comb_ops 8192 x 8192 at keyless size, both over prefixes of the gens_r1cs_eval stream.  Uniform Fr scalars, sampled rows
+    against the oracle, bucket method and lookup table."""
+    import torch
+    bases, gxy = ctx.gens_new(R, b"gens_r1cs_eval")
+    try:
+        Z = torch.empty(32 * L * R, dtype=torch.uint8, device="cuda")
+        ctx.scalars_synthetic(77, 0, L * R, Z.data_ptr())
+        out, infs = ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, R)
+        assert not any(infs)
+        Zv = Z.view(L, R * 32)
+        for i in rows:
+            assert out[64 * i:64 * i + 64] == ol.commit(Zv[i].cpu().numpy().tobytes(), bytes(32), gxy[:64 * R], gxy[64 * R:])
+        ctx.bases_precompute(bases, 100 << 30)
+        out2, infs2 = ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, R)
+        assert out2 == out and infs2 == infs
+    finally:
+        bases.free()

@@ -444,7 +444,7 @@ def test_bind_many_both_paths(ctx, ol, count):
         t.free()
 
 
-@pytest.mark.parametrize("logn", [1, 2, 9])
+@pytest.mark.parametrize("logn", [1, 2, 9, 12, 15])        # 12, 15: streaming layers first, then the <= 2048-entry tail in one launch
 def test_product_circuit_one_call(ctx, ol, sbn, logn):
     """ProductCircuit::new (product_tree.rs:39-57) in one call == repeated compute_layer (oracle), down to the product itself"""
     n = 1 << logn
@@ -462,3 +462,46 @@ def test_product_circuit_one_call(ctx, ol, sbn, logn):
     with pytest.raises(sbn.SbnError):
         ctx.product_circuit(one)
     one.free(); t.free()
+
+
+def test_reference_product_tree_known_answers(ctx, pr):
+    """the reference's own unit-test values (product_tree.rs:544-590): ProductCircuit over [2, 3, 5, 7] evaluates to 210;
+    DotProductCircuit([1,2,3,4], [5,6,7,8], weights 1) evaluates to 70"""
+    t = ctx.table_upload(fr_bytes([2, 3, 5, 7]))
+    layers = ctx.product_circuit(t)
+    assert [len(x) for x in layers] == [2, 1]
+    assert ctx.table_download(layers[0]) == fr_bytes([10, 21])            # compute_layer: left half * right half (product_tree.rs:21-37)
+    assert ctx.table_download(layers[-1]) == fr_bytes([210])
+    for x in layers:
+        x.free()
+    t.free()
+    left, right, weight = (ctx.table_upload(fr_bytes(v)) for v in ([1, 2, 3, 4], [5, 6, 7, 8], [1, 1, 1, 1]))
+    assert ctx.table_dot(left, right) == fr_bytes([70])
+    # through the cubic round sums: e0 = the lower half of the index range (sumcheck.rs:111-135), e0 + e1 = the circuit's value
+    ev = ctx.sc_eval_cubic(left, right, weight)
+    assert int.from_bytes(ev[:32], "little") == 1 * 5 + 2 * 6
+    for x in (left, right, weight):
+        x.free()
+
+
+def test_fused_round_unspilled_build(sbn, ol):
+    """SBN_SC_WAVES=3 selects the 3-waves-per-SIMD build of the streaming fused round (no spills); same values"""
+    import os
+    n = 1 << 16
+    A, B, C = (rand_scalars(n, s + 77) for s in (1, 2, 3))
+    r = rand_scalars(1, 78)
+    os.environ["SBN_SC_WAVES"] = "3"
+    try:
+        cx = sbn.Context(0)
+    finally:
+        del os.environ["SBN_SC_WAVES"]
+    try:
+        tA, tB, tC = (cx.table_upload(x) for x in (A, B, C))
+        got = cx.sc_bind_eval_cubic_batched([tA, tB], [tB, tA], [tC, tC], r)
+        bA, bB, bC = (ol.bind_top(x, r) for x in (A, B, C))
+        assert got == ol.sc_eval_cubic(bA, bB, bC) + ol.sc_eval_cubic(bB, bA, bC)
+        assert cx.table_download(tC) == bC
+        for t in (tA, tB, tC):
+            t.free()
+    finally:
+        cx.close()

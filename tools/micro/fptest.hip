@@ -28,6 +28,7 @@ template <class M> __global__ void k_check(const uint32_t* in, uint32_t* bad, in
   int i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
   Fe<M> a = fe_load<M>(in + 16 * (size_t)i), b = fe_load<M>(in + 16 * (size_t)i + 8);
   Fe<M> x = fe_mul<M>(a, b), y = ref_mul<M>(a, b);
+  if (!fe_eq<M>(fe_mul_deferred<M>(a, b), y)) atomicAdd(bad, 1);
   Fe<M> s = fe_add<M>(a, b), d = fe_sub<M>(s, b);   // (a+b)-b == a
   Fe<M> n0 = fe_add<M>(a, fe_neg<M>(a));
   Fe<M> rt = fe_from_mont<M>(fe_to_mont<M>(a));
@@ -45,6 +46,7 @@ template <class M, int VAR> __global__ void __launch_bounds__(256) k_rate(uint32
   Fe<M> a = fe_load<M>(in + 16 * threadIdx.x), b = fe_load<M>(in + 16 * threadIdx.x + 8);
   for (int i = 0; i < MM_ITERS; i++) {
     if (VAR == 0) { a = fe_mul<M>(a, b); b = fe_mul<M>(b, a); }
+    else if (VAR == 2) { a = fe_mul_deferred<M>(a, b); b = fe_mul_deferred<M>(b, a); }
     else { a = ref_mul<M>(a, b); b = ref_mul<M>(b, a); }
   }
   uint32_t r = 0; for (int j = 0; j < 8; j++) r ^= a.v[j] ^ b.v[j];
@@ -86,7 +88,7 @@ template <class K> void rate(const char* name, K kern, int blocks, double ops, u
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
   double tot = ops * blocks * 256.0;
-  printf("%-14s blocks=%5d %.3f ms %.3e ops/s  %.0f cyc/op/wave@2.4GHz\n", name, blocks, ms, tot / (ms * 1e-3), (ms * 1e-3) * 2.4e9 * 1024 / (tot / 64));
+  printf("%-17s blocks=%5d %.3f ms %.3e ops/s  %.0f cyc/op/wave@2.4GHz\n", name, blocks, ms, tot / (ms * 1e-3), (ms * 1e-3) * 2.4e9 * 1024 / (tot / 64));
 }
 int main() {
   const int n = 1 << 20;
@@ -105,9 +107,10 @@ int main() {
     CK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
     printf("%s inv check: %u mismatches of 4096\n", f ? "Fr" : "Fq", bad); fails += bad;
   }
-  for (int occ : {1, 2, 4, 8}) {
+  for (int occ : {1, 2, 3, 4, 8}) {      // occ = waves per SIMD (256-thread blocks per CU)
     rate("fe_mul(asm)", k_rate<FqP, 0>, 256 * occ, 2.0 * MM_ITERS, d_o, d_in);
-    rate("fe_mul(C cios)", k_rate<FqP, 1>, 256 * occ, 2.0 * MM_ITERS, d_o, d_in);
+    rate("fe_mul(deferred)", k_rate<FqP, 2>, 256 * occ, 2.0 * MM_ITERS, d_o, d_in);
+    if (occ == 1 || occ == 8) rate("fe_mul(C cios)", k_rate<FqP, 1>, 256 * occ, 2.0 * MM_ITERS, d_o, d_in);
     rate("fe_add+sub", k_rate_add<FqP>, 256 * occ, 8.0 * MM_ITERS, d_o, d_in);
   }
   printf(fails ? "FPTEST FAIL\n" : "FPTEST OK\n");
