@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
     xyzz_madd(Q, P, false);                              // (64 a + k + 1) * P: never infinity (prime order, multiplier < r)
     xyzz_store(tmp_xyzz + 32 * ((size_t)k * lanes + tl), Q);
     run = fe_mul(run, fe_mul(Q.ZZ, Q.ZZZ));
-    fe_store<FqP>(tmp_pref + 8 * ((size_t)k * lanes + tl), run);
+    fe_store_packed<FqP>(tmp_pref + 8 * ((size_t)k * lanes + tl), fe_fix_nonneg<FqP, 1>(run));
   }
   Fq inv = fe_inv(run);
   for (int k = COMB_CH - 1; k >= 0; k--) {

@@ -1,6 +1,7 @@
 // ctx.hpp — context, workspace and per-kernel profiling of libsbn254_hip.so (included by sbn254.hip only).
 #pragma once
 // ------------------------------------------------------------------------------------------------
+static const uint32_t SBN_SCALARS_INTERNAL = 0x10000u;   // private flag: the scalars are one of this library's device tables (Montgomery R = 2^261, lazy representatives)
 struct ProfEntry { std::string name; double ms = 0; uint64_t launches = 0; };
 struct PendingEvt { int idx; hipEvent_t e0, e1; };
 

@@ -9,20 +9,26 @@
 // reference's generator derivation makes ~66 % of its bases literally equal to G
 // (group.rs:110-131 falls back to 1*G when the hash is >= r), so equal and opposite
 // operands are the COMMON case on the real workload, not a corner.
+//
+// Field values are lazy (fp.cuh): coordinates are kept NORMALISED and NON-NEGATIVE with these value ranges, which the two hot
+// formulas (xyzz_madd, xyzz_add_inl: fp.cuh's unsigned fast path) rely on and re-establish:
+//      X in [0, 5.2p)    Y in [0, 3.2p)    ZZ, ZZZ in [0, 1.2p)    affine x, y in [0, p) (tables are canonical)
+// Infinity is the exact all-zero limb pattern of ZZ (XYZZ) or of x and y (affine); no computed non-identity point ever has it
+// (its ZZ is a product of non-zero elements), and the memory formats below keep zero as zero.
 #pragma once
 #include "fp.cuh"
 
 namespace sbn {
 
-struct alignas(16) Affine {   // 64 B; infinity is encoded as x = y = 0 ((0,0) is not on the curve)
+struct Affine {   // memory: 64 B canonical x || y; infinity is encoded as x = y = 0 ((0,0) is not on the curve)
   Fq x, y;
 };
-struct alignas(16) XYZZ {     // 128 B; infinity <=> ZZ == 0
+struct XYZZ {     // memory: 128 B; infinity <=> ZZ == 0
   Fq X, Y, ZZ, ZZZ;
 };
 
-__device__ __forceinline__ bool aff_is_inf(const Affine& p) { return fe_is_zero(p.x) && fe_is_zero(p.y); }
-__device__ __forceinline__ bool xyzz_is_inf(const XYZZ& p) { return fe_is_zero(p.ZZ); }
+__device__ __forceinline__ bool aff_is_inf(const Affine& p) { return fe_is_zero_limbs(p.x) && fe_is_zero_limbs(p.y); }
+__device__ __forceinline__ bool xyzz_is_inf(const XYZZ& p) { return fe_is_zero_limbs(p.ZZ); }
 __device__ __forceinline__ XYZZ xyzz_inf() { XYZZ r; r.X = fe_zero<FqP>(); r.Y = fe_zero<FqP>(); r.ZZ = fe_zero<FqP>(); r.ZZZ = fe_zero<FqP>(); return r; }
 __device__ __forceinline__ XYZZ xyzz_from_affine(const Affine& p) {
   XYZZ r; r.X = p.x; r.Y = p.y;
@@ -33,110 +39,105 @@ __device__ __forceinline__ XYZZ xyzz_from_affine(const Affine& p) {
 __device__ __forceinline__ Affine aff_load(const void* p) {
   Affine a; a.x = fe_load<FqP>(p); a.y = fe_load<FqP>(reinterpret_cast<const uint8_t*>(p) + 32); return a;
 }
-__device__ __forceinline__ void aff_store(void* p, const Affine& a) {
+__device__ __forceinline__ void aff_store(void* p, const Affine& a) {      // canonical (tables, results)
   fe_store<FqP>(p, a.x); fe_store<FqP>(reinterpret_cast<uint8_t*>(p) + 32, a.y);
 }
 __device__ __forceinline__ XYZZ xyzz_load(const void* p) {
   const uint8_t* q = reinterpret_cast<const uint8_t*>(p);
   XYZZ r; r.X = fe_load<FqP>(q); r.Y = fe_load<FqP>(q + 32); r.ZZ = fe_load<FqP>(q + 64); r.ZZZ = fe_load<FqP>(q + 96); return r;
 }
+// Intermediate sums (buckets, partial sums) are stored as they are — non-negative representatives below 2^256 = 5.29 p, not
+// canonical ones (the sign masks below are a safety net for values that came through the signed, rare-path formulas).
 __device__ __forceinline__ void xyzz_store(void* p, const XYZZ& a) {
   uint8_t* q = reinterpret_cast<uint8_t*>(p);
-  fe_store<FqP>(q, a.X); fe_store<FqP>(q + 32, a.Y); fe_store<FqP>(q + 64, a.ZZ); fe_store<FqP>(q + 96, a.ZZZ);
+  fe_store_packed<FqP>(q, fe_fix_nonneg<FqP, 4>(fe_norm(a.X))); fe_store_packed<FqP>(q + 32, fe_fix_nonneg<FqP, 2>(fe_norm(a.Y)));
+  fe_store_packed<FqP>(q + 64, fe_fix_nonneg<FqP, 1>(fe_norm(a.ZZ))); fe_store_packed<FqP>(q + 96, fe_fix_nonneg<FqP, 1>(fe_norm(a.ZZZ)));
 }
 
-// 2*P for an affine P != infinity (y != 0 always holds on this curve: no 2-torsion in G1).
-// Inlined on purpose: an out-of-line callee takes its 64/128-byte operand by reference, which forces the caller to keep a copy
-// in scratch memory on EVERY loop iteration even though the doubling branch is rare (measured: ~1 GB of scratch stores per
-// 2^20 MSM in the accumulate kernel).
+// 2*P for an affine P != infinity (y != 0 always holds on this curve: no 2-torsion in G1).  Rare path: the safe (signed,
+// normalising) operations, then the coordinates are brought back to the non-negative form the hot formulas expect.
+// Inlined on purpose: an out-of-line callee takes its operand by reference, which forces the caller to keep a copy in scratch memory.
 __device__ __forceinline__ XYZZ xyzz_dbl_affine(const Affine& p) {
-  Fq U = fe_dbl(p.y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.x, V);
-  Fq xx = fe_sqr(p.x), M3 = fe_add(fe_dbl(xx), xx);
+  const Fq U = fe_dbl(p.y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.x, V);
+  const Fq xx = fe_sqr(p.x), M3 = fe_add(fe_dbl(xx), xx);
   XYZZ r;
-  r.X = fe_sub(fe_sub(fe_sqr(M3), S), S);
-  r.Y = fe_sub(fe_mul(M3, fe_sub(S, r.X)), fe_mul(W, p.y));
-  r.ZZ = V; r.ZZZ = W;
+  const Fq X = fe_sub(fe_sub(fe_sqr(M3), S), S);                                  // (-2.2p, 1.1p)
+  r.X = fe_fix_nonneg<FqP, 4>(X);
+  r.Y = fe_fix_nonneg<FqP, 2>(fe_sub(fe_mul(M3, fe_sub(S, X)), fe_mul(W, p.y)));  // (-1.2p, 1.2p)
+  r.ZZ = fe_fix_nonneg<FqP, 1>(V); r.ZZZ = fe_fix_nonneg<FqP, 1>(W);
   return r;
 }
 // 2*P, XYZZ
 __device__ __forceinline__ XYZZ xyzz_dbl(const XYZZ& p) {
   if (xyzz_is_inf(p)) return p;
-  Fq U = fe_dbl(p.Y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.X, V);
-  Fq xx = fe_sqr(p.X), M3 = fe_add(fe_dbl(xx), xx);
+  const Fq U = fe_dbl(p.Y), V = fe_sqr(U), W = fe_mul(U, V), S = fe_mul(p.X, V);
+  const Fq xx = fe_sqr(p.X), M3 = fe_add(fe_dbl(xx), xx);
   XYZZ r;
-  r.X = fe_sub(fe_sub(fe_sqr(M3), S), S);
-  r.Y = fe_sub(fe_mul(M3, fe_sub(S, r.X)), fe_mul(W, p.Y));
-  r.ZZ = fe_mul(V, p.ZZ); r.ZZZ = fe_mul(W, p.ZZZ);
+  const Fq X = fe_sub(fe_sub(fe_sqr(M3), S), S);
+  r.X = fe_fix_nonneg<FqP, 4>(X);
+  r.Y = fe_fix_nonneg<FqP, 2>(fe_sub(fe_mul(M3, fe_sub(S, X)), fe_mul(W, p.Y)));
+  r.ZZ = fe_fix_nonneg<FqP, 1>(fe_mul(V, p.ZZ)); r.ZZZ = fe_fix_nonneg<FqP, 1>(fe_mul(W, p.ZZZ));
   return r;
 }
 
-// acc += q (q affine, possibly infinity); neg => acc -= q.  8M + 2S on the common path.
+// acc += q (q affine from a table: canonical, possibly infinity); neg => acc -= q.  8M + 2S on the common path, on the UNSIGNED
+// fast path of fp.cuh: every difference carries an inflated multiple of p, so no limb is ever negative; four carry passes.
+// Value ranges (re-established here): X in [0, 5.2p), Y in [0, 3.2p), ZZ, ZZZ in [0, 1.2p); all limbs normalised.
 __device__ __forceinline__ void xyzz_madd(XYZZ& acc, const Affine& q_in, bool neg) {
   if (aff_is_inf(q_in)) return;
-  Affine q = q_in;
-  if (neg) q.y = fe_neg(q.y);
-  if (xyzz_is_inf(acc)) { acc.X = q.x; acc.Y = q.y; acc.ZZ = fe_one<FqP>(); acc.ZZZ = acc.ZZ; return; }
-  Fq U2 = fe_mul(q.x, acc.ZZ), S2 = fe_mul(q.y, acc.ZZZ);
-  Fq P = fe_sub(U2, acc.X), R = fe_sub(S2, acc.Y);
-  if (fe_is_zero(P)) {                         // same x: doubling or cancellation
-    if (fe_is_zero(R)) acc = xyzz_dbl_affine(q); else acc = xyzz_inf();
+  const Fq qy = neg ? fe_negb<FqP, 2>(q_in.y) : q_in.y;                    // 2p - y: limbs below 2^30
+  if (xyzz_is_inf(acc)) { acc.X = q_in.x; acc.Y = fe_normu(qy); acc.ZZ = fe_one<FqP>(); acc.ZZZ = acc.ZZ; return; }
+  const Fq U2 = fe_mulu(q_in.x, acc.ZZ), S2 = fe_mulu(qy, acc.ZZZ);        // [0, 1.2p)
+  const Fq P = fe_normu(fe_subb<FqP, 6, 1>(U2, acc.X));                    // U2 - X + 6p in (0.8p, 7.2p)
+  const Fq R = fe_normu(fe_subb<FqP, 4, 1>(S2, acc.Y));                    // S2 - Y + 4p in (0.8p, 5.2p)
+  if (fe_maybe_zero(P) && fe_is_zero(P)) {                                 // same x: doubling or cancellation
+    if (fe_is_zero(R)) { Affine q; q.x = q_in.x; q.y = fe_normu(qy); acc = xyzz_dbl_affine(q); } else acc = xyzz_inf();
     return;
   }
-  Fq PP = fe_sqr(P), PPP = fe_mul(P, PP), Q = fe_mul(acc.X, PP);
-  Fq X3 = fe_sub(fe_sub(fe_sub(fe_sqr(R), PPP), Q), Q);
-  Fq Y3 = fe_sub(fe_mul(R, fe_sub(Q, X3)), fe_mul(acc.Y, PPP));
-  acc.X = X3; acc.Y = Y3; acc.ZZ = fe_mul(acc.ZZ, PP); acc.ZZZ = fe_mul(acc.ZZZ, PPP);
+  const Fq PP = fe_squ(P), PPP = fe_mulu(P, PP), Q = fe_mulu(acc.X, PP);
+  const Fq X3 = fe_normu(fe_subb<FqP, 4, 3>(fe_squ(R), fe_add_lazy(fe_add_lazy(PPP, Q), Q)));        // R^2 - PPP - 2Q + 4p in (0.4p, 5.2p)
+  const Fq Y3 = fe_normu(fe_subb<FqP, 2, 1>(fe_mulu(R, fe_subb<FqP, 6, 1>(Q, X3)), fe_mulu(acc.Y, PPP)));   // in (0.8p, 3.2p)
+  acc.X = X3; acc.Y = Y3; acc.ZZ = fe_mulu(acc.ZZ, PP); acc.ZZZ = fe_mulu(acc.ZZZ, PPP);
 }
 
-// a + b, both XYZZ.  12M + 2S on the common path.  The inlined form is for the latency-bound reduction kernels (a call
-// passes both 128-byte operands through scratch); xyzz_add is the out-of-line copy for code-size-sensitive callers.
+// a + b, both XYZZ (normalised, non-negative, ranges as above).  12M + 2S on the common path.  The inlined form is for the
+// latency-bound reduction kernels (a call passes both operands through scratch); xyzz_add is the out-of-line copy.
 __device__ __forceinline__ XYZZ xyzz_add_inl(const XYZZ& a, const XYZZ& b) {
   if (xyzz_is_inf(a)) return b;
   if (xyzz_is_inf(b)) return a;
-  Fq U1 = fe_mul(a.X, b.ZZ), U2 = fe_mul(b.X, a.ZZ), S1 = fe_mul(a.Y, b.ZZZ), S2 = fe_mul(b.Y, a.ZZZ);
-  Fq P = fe_sub(U2, U1), R = fe_sub(S2, S1);
-  if (fe_is_zero(P)) {
+  const Fq U1 = fe_mulu(a.X, b.ZZ), U2 = fe_mulu(b.X, a.ZZ), S1 = fe_mulu(a.Y, b.ZZZ), S2 = fe_mulu(b.Y, a.ZZZ);   // [0, 1.2p)
+  const Fq P = fe_normu(fe_subb<FqP, 2, 1>(U2, U1)), R = fe_normu(fe_subb<FqP, 2, 1>(S2, S1));                  // (0.8p, 3.2p)
+  if (fe_maybe_zero(P) && fe_is_zero(P)) {
     if (fe_is_zero(R)) return xyzz_dbl(a);
     return xyzz_inf();
   }
-  Fq PP = fe_sqr(P), PPP = fe_mul(P, PP), Q = fe_mul(U1, PP);
+  const Fq PP = fe_squ(P), PPP = fe_mulu(P, PP), Q = fe_mulu(U1, PP);
   XYZZ r;
-  r.X = fe_sub(fe_sub(fe_sub(fe_sqr(R), PPP), Q), Q);
-  r.Y = fe_sub(fe_mul(R, fe_sub(Q, r.X)), fe_mul(S1, PPP));
-  r.ZZ = fe_mul(fe_mul(a.ZZ, b.ZZ), PP);
-  r.ZZZ = fe_mul(fe_mul(a.ZZZ, b.ZZZ), PPP);
+  r.X = fe_normu(fe_subb<FqP, 4, 3>(fe_squ(R), fe_add_lazy(fe_add_lazy(PPP, Q), Q)));
+  r.Y = fe_normu(fe_subb<FqP, 2, 1>(fe_mulu(R, fe_subb<FqP, 6, 1>(Q, r.X)), fe_mulu(S1, PPP)));
+  r.ZZ = fe_mulu(fe_mulu(a.ZZ, b.ZZ), PP);
+  r.ZZZ = fe_mulu(fe_mulu(a.ZZZ, b.ZZZ), PPP);
   return r;
 }
 __device__ __noinline__ XYZZ xyzz_add(const XYZZ& a, const XYZZ& b) { return xyzz_add_inl(a, b); }
 
-// canonical affine (Montgomery coordinates) from XYZZ: one inversion
+// canonical affine (Montgomery coordinates in [0, p)) from XYZZ: one inversion
 __device__ __noinline__ Affine xyzz_to_affine(const XYZZ& p) {
   Affine r;
   if (xyzz_is_inf(p)) { r.x = fe_zero<FqP>(); r.y = fe_zero<FqP>(); return r; }
-  Fq I = fe_inv(fe_mul(p.ZZ, p.ZZZ));           // 1/(ZZ*ZZZ)
-  r.x = fe_mul(p.X, fe_mul(I, p.ZZZ));          // X / ZZ
-  r.y = fe_mul(p.Y, fe_mul(I, p.ZZ));           // Y / ZZZ
+  const Fq I = fe_inv(fe_mul(p.ZZ, p.ZZZ));        // 1/(ZZ*ZZZ)
+  r.x = fe_canon(fe_mul(p.X, fe_mul(I, p.ZZZ)));   // X / ZZ
+  r.y = fe_canon(fe_mul(p.Y, fe_mul(I, p.ZZ)));    // Y / ZZZ
   return r;
 }
 
 // lane <- lane+delta exchange of a whole point inside one 64-wide wavefront
 __device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& p, int delta) {
-  XYZZ r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    r.X.v[i] = __shfl_down(p.X.v[i], delta, 64); r.Y.v[i] = __shfl_down(p.Y.v[i], delta, 64);
-    r.ZZ.v[i] = __shfl_down(p.ZZ.v[i], delta, 64); r.ZZZ.v[i] = __shfl_down(p.ZZZ.v[i], delta, 64);
-  }
+  XYZZ r; r.X = fe_shfl_down(p.X, delta); r.Y = fe_shfl_down(p.Y, delta); r.ZZ = fe_shfl_down(p.ZZ, delta); r.ZZZ = fe_shfl_down(p.ZZZ, delta);
   return r;
 }
-
 __device__ __forceinline__ XYZZ xyzz_shfl_xor(const XYZZ& p, int mask) {
-  XYZZ r;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    r.X.v[i] = __shfl_xor(p.X.v[i], mask, 64); r.Y.v[i] = __shfl_xor(p.Y.v[i], mask, 64);
-    r.ZZ.v[i] = __shfl_xor(p.ZZ.v[i], mask, 64); r.ZZZ.v[i] = __shfl_xor(p.ZZZ.v[i], mask, 64);
-  }
+  XYZZ r; r.X = fe_shfl_xor(p.X, mask); r.Y = fe_shfl_xor(p.Y, mask); r.ZZ = fe_shfl_xor(p.ZZ, mask); r.ZZZ = fe_shfl_xor(p.ZZZ, mask);
   return r;
 }
 

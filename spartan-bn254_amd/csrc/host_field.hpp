@@ -73,7 +73,13 @@ static inline Fq to_mont(const Fq& a) { Fq r2; memcpy(r2.v, QR2, 32); return mul
 
 // XYZZ point, same layout as the device's (4 x 32 B, Montgomery limbs little-endian)
 struct Pt { Fq X, Y, ZZ, ZZZ; };
+// The device's field layer (fp.cuh) keeps Montgomery form with R = 2^261 and stores lazy representatives (any non-negative
+// integer below 2^256 congruent to x * 2^261); this file's CIOS uses R = 2^256 and canonical values.  One product with 2^251
+// converts: (x 2^261 + k p) * 2^251 * 2^-256 = x * 2^256 (mod p), and the CIOS result is canonical for any 256-bit left operand.
+static const uint64_t QK251[4] = {0, 0, 0, 0x0800000000000000ull};
+static inline Fq from_device(const Fq& a) { Fq k; memcpy(k.v, QK251, 32); return mul(a, k); }
 static inline bool is_inf(const Pt& p) { return is_zero(p.ZZ); }
+static inline Pt pt_from_device(const Pt& d) { Pt p; p.X = from_device(d.X); p.Y = from_device(d.Y); p.ZZ = from_device(d.ZZ); p.ZZZ = from_device(d.ZZZ); return p; }
 static inline Pt inf() { Pt p; p.X = zero(); p.Y = zero(); p.ZZ = zero(); p.ZZZ = zero(); return p; }
 static inline Pt pdbl(const Pt& p) {
   if (is_inf(p)) return p;

@@ -183,8 +183,9 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
   if (c->prof) prof_drain(c);
   if ((rc = input_check_end(c))) return rc;
   // sum_w 2^(c w) S_w: the 254-doubling serial chain, on the host
-  const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
-  sbn_host::Pt total = sbn_host::combine_windows(S, J.s.W, J.s.c);
+  std::vector<sbn_host::Pt> S((size_t)J.s.W);
+  for (int w = 0; w < J.s.W; w++) S[(size_t)w] = sbn_host::pt_from_device(((const sbn_host::Pt*)c->pin)[w]);
+  sbn_host::Pt total = sbn_host::combine_windows(S.data(), J.s.W, J.s.c);
   sbn_host::to_affine_bytes(total, out_xy, out_is_inf);
   return SBN_OK;
 }
@@ -347,7 +348,7 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if (c->prof) prof_drain(c);
     if ((rc = input_check_end(c))) return rc;
     const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
-    for (size_t i = 0; i < L; i++) { int inf = 0; sbn_host::to_affine_bytes(S[i], out_xy + 64 * i, &inf); if (out_inf) out_inf[i] = (uint8_t)inf; }
+    for (size_t i = 0; i < L; i++) { int inf = 0; sbn_host::to_affine_bytes(sbn_host::pt_from_device(S[i]), out_xy + 64 * i, &inf); if (out_inf) out_inf[i] = (uint8_t)inf; }
     return SBN_OK;
   }
   if ((rc = ensure(c, c->out_small, L * 65))) return rc;
@@ -428,10 +429,12 @@ static int bases_build_dedupe(sbn_ctx* c, sbn_bases* b, const std::vector<std::s
     HIPCHK(c, hipMemcpyAsync(c->stage_scal.p, mult.data(), U * 32, hipMemcpyHostToDevice, c->stream));
     uint8_t sxy[64]; int sinf = 0;
     if ((rc2 = msm_device(c, (const uint32_t*)c->stage_scal.p, (const uint32_t*)q->d_pts, U, sxy, &sinf))) return rc2;
-    sbn_host::Fq x, y; memcpy(x.v, sxy, 32); memcpy(y.v, sxy + 32, 32);
     uint8_t sm[64]; memset(sm, 0, 64);
-    if (!sinf) { sbn_host::Fq xm = sbn_host::to_mont(x), ym = sbn_host::to_mont(y); memcpy(sm, xm.v, 32); memcpy(sm + 32, ym.v, 32); }
+    if (!sinf) memcpy(sm, sxy, 64);                  // canonical x || y; the device brings it to its Montgomery form (infinity stays all-zero)
     HIPCHK(c, hipMemcpy((uint8_t*)q->d_pts + 64 * U, sm, 64, hipMemcpyHostToDevice));
+    LAUNCH(c, "k_points_to_mont", k_points_to_mont, 1, 256, (const uint32_t*)q->d_pts + 16 * U, (uint32_t*)q->d_pts + 16 * U, (size_t)1);
+    LAUNCHCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return SBN_OK;
 }

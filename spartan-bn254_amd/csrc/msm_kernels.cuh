@@ -59,8 +59,14 @@ __device__ __forceinline__ int window_digit_indep(const uint32_t* __restrict__ k
 __global__ void __launch_bounds__(256) k_scalars_from_mont(const uint32_t* in, uint32_t* out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr a = fe_load<FrP>(in + 8 * i);
-  fe_store<FrP>(out + 8 * i, fe_from_mont(a));
+  Fr a = fe_load<FrP>(in + 8 * i);                            // ark-ff's limbs: value * 2^256
+  fe_store_packed<FrP>(out + 8 * i, fe_ark_mont_to_plain(a));
+}
+// this library's Montgomery tables (R = 2^261, lazy representatives) -> canonical integers (a table fed to a commitment)
+__global__ void __launch_bounds__(256) k_scalars_from_internal(const uint32_t* in, uint32_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store_packed<FrP>(out + 8 * i, fe_from_mont(fe_load<FrP>(in + 8 * i)));
 }
 // canonical affine points -> Montgomery coordinates
 // (also run in place: no __restrict__)
@@ -68,8 +74,16 @@ __global__ void __launch_bounds__(256) k_points_to_mont(const uint32_t* in, uint
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fq x = fe_load<FqP>(in + 16 * i), y = fe_load<FqP>(in + 16 * i + 8);
-  fe_store<FqP>(out + 16 * i, fe_to_mont(x));
-  fe_store<FqP>(out + 16 * i + 8, fe_to_mont(y));
+  fe_store_packed<FqP>(out + 16 * i, fe_canon_small(fe_to_mont(x)));
+  fe_store_packed<FqP>(out + 16 * i + 8, fe_canon_small(fe_to_mont(y)));
+}
+// ark-ff's in-memory affine coordinates (Montgomery, R = 2^256) -> this library's (R = 2^261); also run in place
+__global__ void __launch_bounds__(256) k_points_from_ark(const uint32_t* in, uint32_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fq x = fe_load<FqP>(in + 16 * i), y = fe_load<FqP>(in + 16 * i + 8);
+  fe_store_packed<FqP>(out + 16 * i, fe_canon_small(fe_from_ark_mont(x)));
+  fe_store_packed<FqP>(out + 16 * i + 8, fe_canon_small(fe_from_ark_mont(y)));
 }
 
 // ---- digit extraction / counting sort ----------------------------------------------------------
@@ -537,7 +551,7 @@ __global__ void __launch_bounds__(64) k_xyzz_to_affine(const uint32_t* __restric
   XYZZ p = xyzz_load(in + 32 * i);
   Affine a = xyzz_to_affine(p);            // (0,0) for infinity
   if (out_mont) aff_store(out_mont + 16 * i, a);
-  if (out_xy) { fe_store<FqP>(out_xy + 16 * i, fe_from_mont(a.x)); fe_store<FqP>(out_xy + 16 * i + 8, fe_from_mont(a.y)); }
+  if (out_xy) { fe_store_packed<FqP>(out_xy + 16 * i, fe_from_mont(a.x)); fe_store_packed<FqP>(out_xy + 16 * i + 8, fe_from_mont(a.y)); }
   if (out_inf) out_inf[i] = xyzz_is_inf(p) ? 1 : 0;
 }
 
@@ -605,8 +619,9 @@ __global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict_
   if (t >= L * W1) return;
   const size_t row = t / W1, u = t - row * W1;
   const bool cst = flags[row] != 0;
-  if (u == U) { fe_store<FrP>(out + 8 * t, cst ? fe_load<FrP>(Z + 8 * row * R) : fe_zero<FrP>()); return; }
-  if (cst) { fe_store<FrP>(out + 8 * t, (u == hcol && blinds) ? fe_load<FrP>(blinds + 8 * row) : fe_zero<FrP>()); return; }
+  // (copies of canonical input scalars are stored as they are; sums go through fe_store, which canonicalises: the digits are cut from them)
+  if (u == U) { fe_store_packed<FrP>(out + 8 * t, cst ? fe_load<FrP>(Z + 8 * row * R) : fe_zero<FrP>()); return; }
+  if (cst) { fe_store_packed<FrP>(out + 8 * t, (u == hcol && blinds) ? fe_load<FrP>(blinds + 8 * row) : fe_zero<FrP>()); return; }
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   if (b - a > big_threshold) return;                     // k_merge_big owns it
   Fr acc = merged_load(Z, blinds, row, R, csr_cols[a]);
@@ -621,15 +636,15 @@ __global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z
   if (flags[row]) return;
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   Fr acc = fe_zero<FrP>();
-  for (uint32_t j = a + threadIdx.x; j < b; j += 64) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
+  uint32_t cnt = 0;
+  for (uint32_t j = a + threadIdx.x; j < b; j += 64) {
+    acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
+    if ((++cnt & 127u) == 0) acc = fe_reduce(acc);                     // lazy values: keep the running sum far below the top limb's range
+  }
+  acc = fe_reduce(acc);
   // wave tree
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    Fr o;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(acc.v[i], d, 64);
-    acc = fe_add(acc, o);
-  }
+  for (int d = 32; d >= 1; d >>= 1) acc = fe_add(acc, fe_shfl_down(acc, d));
   if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * (U + 1) + u), acc);
 }
 
@@ -639,6 +654,7 @@ __global__ void __launch_bounds__(64) k_jacobian_to_affine(const uint32_t* __res
   if (i >= n) return;
   Fq X = fe_load<FqP>(in + 24 * i), Y = fe_load<FqP>(in + 24 * i + 8), Z = fe_load<FqP>(in + 24 * i + 16);
   if (!in_is_mont) { X = fe_to_mont(X); Y = fe_to_mont(Y); Z = fe_to_mont(Z); }
+  else { X = fe_from_ark_mont(X); Y = fe_from_ark_mont(Y); Z = fe_from_ark_mont(Z); }
   Affine a;
   if (fe_is_zero(Z)) { a.x = fe_zero<FqP>(); a.y = a.x; }
   else { const Fq zi = fe_inv(Z), zi2 = fe_sqr(zi); a.x = fe_mul(X, zi2); a.y = fe_mul(Y, fe_mul(zi2, zi)); }
@@ -701,8 +717,8 @@ __global__ void __launch_bounds__(256) k_scalars_synthetic(unsigned long long se
 __global__ void __launch_bounds__(256) k_points_from_mont(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fe_store<FqP>(out + 16 * i, fe_from_mont(fe_load<FqP>(in + 16 * i)));
-  fe_store<FqP>(out + 16 * i + 8, fe_from_mont(fe_load<FqP>(in + 16 * i + 8)));
+  fe_store_packed<FqP>(out + 16 * i, fe_from_mont(fe_load<FqP>(in + 16 * i)));
+  fe_store_packed<FqP>(out + 16 * i + 8, fe_from_mont(fe_load<FqP>(in + 16 * i + 8)));
 }
 
 }  // namespace sbn
