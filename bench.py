@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 R_MOD = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
-MADD_PEAK = 1.2e10             # xyzz mixed additions/s with operands in registers, whole chip (tools/micro/ecbench.hip, measured on MI355X)
+MADD_PEAK = 1.46e10            # xyzz mixed additions/s with operands in registers, whole chip (tools/micro/ecbench.hip, measured on MI355X, 9x29-bit field layer)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable streaming)
 S0 = 0x1234567890abcdef1234567890abcdef
 DSTEP = 0x0fedcba987654321
@@ -418,7 +418,7 @@ def main():
             my_rows = sharding.shard_rows(L, rank, world)
             Zl = Z.view(L, Rc * 32)[rank::world].contiguous() if world > 1 else Z
             nl = len(my_rows)
-            res = {"shape": f"{L}x{Rc}", "scalars": "uniform in Fr (SplitMix64 mod r), rows >= 3L/4 zero", "generators": "MultiCommitGens::new(8192, b'gens_r1cs_eval') (commitments.rs:31-62): 2813 unique points + h",
+            res = {"shape": f"{L}x{Rc}", "scalars": "uniform in Fr (SplitMix64 mod r), rows >= 3L/4 zero", "generators": "MultiCommitGens::new(cols, b'gens_r1cs_eval') (commitments.rs:31-62; 2813 unique points + h at 8192 columns)",
                    "rows_per_rank": nl, "sharding": "interleaved rows of ONE matrix, gather_rows" if world > 1 else None,
                    "algorithmic_bytes_per_pair": round((L * Rc * 32.0 + (Rc + 1) * 64.0 + L * 64.0) / (L * Rc), 3)}
 

@@ -54,8 +54,12 @@ __device__ __forceinline__ Fr fr_load_coherent(const uint32_t* p) {   // written
   for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return fe_unpack<FrP>(w);
 }
+constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
 // The block's three running sums -> partial[(inst * gridDim.x + blockIdx.x) * 3 + q] (memory format, Montgomery domain).
-__device__ __forceinline__ void sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial) {
+// mbox != nullptr with ONE block per instance (the tables of the last ~8 rounds): the block's sums are the round's values, so
+// they go straight to the host mailbox as canonical integers and the flag follows — no partial sums, no ticket, no device fence.
+// Returns true when it finished the round that way.
+__device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq) {
   __shared__ uint32_t sm[4][3][NL];
   e0 = wave_sum_fr(fe_reduce(e0)); e2 = wave_sum_fr(fe_reduce(e2));
   if (three) e3 = wave_sum_fr(fe_reduce(e3));
@@ -65,16 +69,22 @@ __device__ __forceinline__ void sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
     for (int k = 0; k < NL; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
   }
   __syncthreads();
+  const bool direct = mbox != nullptr && gridDim.x == 1;
   if (threadIdx.x < 3) {
     Fr s = fe_zero<FrP>();
     for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
-    fe_store_tab<FrP>(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
+    if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + threadIdx.x), fe_from_mont(s));
+    else fe_store_tab<FrP>(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
   }
+  if (direct) {
+    __syncthreads();                           // the three stores happen-before the flag's release
+    if (threadIdx.x == 0) __hip_atomic_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return direct;
 }
-// Called by all 256 threads after the block's triple went to partial[...].  nq = 2 or 3.
+// Called by all 256 threads after the block's triple went to partial[...] (several blocks per instance).  nq = 2 or 3.
 // `out` = mailbox in coherent pinned host memory: 24 x 96 B of results, then one flag word per instance; the flag is stored
 // (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
-constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
 __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
   __shared__ uint32_t s_last;
   __threadfence();                         // the triple is visible device-wide before the ticket is taken
@@ -88,9 +98,9 @@ __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ 
     Fr s = fe_zero<FrP>();
     if (wv < nq) for (unsigned b = lane; b < gridDim.x; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + b) * 3 + wv)));
     s = wave_sum_fr(fe_reduce(s));
-    if (lane == 0) { fe_store_packed<FrP>(out + 8 * ((size_t)blockIdx.y * 3 + wv), fe_from_mont(s)); __threadfence_system(); }
+    if (lane == 0) fe_store_packed<FrP>(out + 8 * ((size_t)blockIdx.y * 3 + wv), fe_from_mont(s));
   }
-  __syncthreads();
+  __syncthreads();                           // the three waves' stores happen-before the one release below
   if (threadIdx.x == 0) {
     tickets[blockIdx.y] = 0;                          // ready for the next launch
     __hip_atomic_store(out + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -103,6 +113,15 @@ struct ScPts { Fr v2, v3; };
 __device__ __forceinline__ ScPts sc_points(const Fr& lo, const Fr& hi) {
   const Fr d = fe_sub_lazy(hi, lo);
   ScPts o; o.v2 = fe_norm(fe_add_lazy(hi, d)); o.v3 = fe_norm(fe_add_lazy(o.v2, d));
+  return o;
+}
+// The same on fp.cuh's unsigned fast path, for table values in [0, 2.01 r) (what this library's sumcheck tables hold): the
+// difference carries 3r, so v2 = 2 hi - lo + 3r < 7r and v3 = 3 hi - 2 lo + 6r < 12r, all limbs non-negative
+// (12r * 12r = 144 r^2 is inside the product's 169 r^2 operand limit).
+__device__ __forceinline__ ScPts sc_points_u(const Fr& lo, const Fr& hi) {
+  const Fr d = fe_subb<FrP, 3, 1>(hi, lo);
+  const Fr v2 = fe_add_lazy(hi, d);
+  ScPts o; o.v2 = fe_normu(v2); o.v3 = fe_normu(fe_add_lazy(v2, d));
   return o;
 }
 
@@ -130,10 +149,10 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
       const Fr al = fe_gload<FrP>(a.t[0] + 8 * i), ah = fe_gload<FrP>(a.t[0] + 8 * (i + half));
       const Fr bl = fe_gload<FrP>(a.t[1] + 8 * i), bh = fe_gload<FrP>(a.t[1] + 8 * (i + half));
       const Fr cl = fe_gload<FrP>(a.t[2] + 8 * i), ch = fe_gload<FrP>(a.t[2] + 8 * (i + half));
-      const ScPts pa = sc_points(al, ah), pb = sc_points(bl, bh), pc = sc_points(cl, ch);
-      fr_acc(e0, fe_mul(fe_mul(al, bl), cl), c0);
-      fr_acc(e2, fe_mul(fe_mul(pa.v2, pb.v2), pc.v2), c2);
-      fr_acc(e3, fe_mul(fe_mul(pa.v3, pb.v3), pc.v3), c3);
+      const ScPts pa = sc_points_u(al, ah), pb = sc_points_u(bl, bh), pc = sc_points_u(cl, ch);
+      fr_acc(e0, fe_mulu(fe_mulu(al, bl), cl), c0);
+      fr_acc(e2, fe_mulu(fe_mulu(pa.v2, pb.v2), pc.v2), c2);
+      fr_acc(e3, fe_mulu(fe_mulu(pa.v3, pb.v3), pc.v3), c3);
     } else {
       const Fr tl = fe_gload<FrP>(a.t[0] + 8 * i), th = fe_gload<FrP>(a.t[0] + 8 * (i + half));
       const Fr al = fe_gload<FrP>(a.t[1] + 8 * i), ah = fe_gload<FrP>(a.t[1] + 8 * (i + half));
@@ -145,7 +164,7 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
       fr_acc(e3, fe_mul(pt.v3, fe_sub(fe_mul(pa.v3, pb.v3), pc.v3)), c3);
     }
   }
-  sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial);
+  if (sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, tickets ? out : nullptr, seq)) return;
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
@@ -168,8 +187,16 @@ struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
 
 // z0 + r (z2 - z0) as the table representative in [0, 2.5 r) that is stored and used: z0, z2 are table values (normalised,
 // below 2.5 r), their limb-wise difference is a legal product operand, the product lies in (-0.1 r, 1.1 r)
+// On the unsigned fast path: table values lie in [0, 2.01 r) (normalised), the difference carries 3r, the product of the
+// canonical challenge with it lies in [0, 1.1 r), and the sum (< 3.1 r) drops 2r when its top limb says it reached 2r — decided on
+// the un-carried top limb (the lower limbs add at most one unit to it), so one carry pass serves the sum and the correction.
 __device__ __forceinline__ Fr sc_bind1(const Fr& z0, const Fr& z2, const Fr& r) {
-  return fe_fix_tab<FrP>(fe_norm(fe_add_lazy(z0, fe_mul(r, fe_sub_lazy(z2, z0)))));
+  Fr x = fe_add_lazy(z0, fe_mulu(r, fe_subb<FrP, 3, 1>(z2, z0)));
+  constexpr int32_t P8 = (int32_t)FrP::P29[8];
+  const uint32_t big = (uint32_t)((2 * P8 + 1 - (int32_t)x.v[NL - 1]) >> 31);          // top >= 2 P8 + 2: value > 2r
+#pragma unroll
+  for (int k = 0; k < NL; k++) x.v[k] -= kp29<FrP, 2>(k) & big;
+  return fe_norm(x);                                                                    // (limbs may have dipped below zero: signed carries)
 }
 // one table at index i: bound values lo = Z'[i], hi = Z'[i + q]
 struct ScPair { Fr lo, hi; };
@@ -188,9 +215,14 @@ struct ScProd { Fr p0, p2, p3; };
 template <int KIND> __device__ __forceinline__ void sc_first(ScProd& P, const ScPair& t) {
   P.p0 = t.lo;
   if (KIND == KIND_QUAD) { P.p2 = fe_norm(fe_sub_lazy(fe_dbl_lazy(t.hi), t.lo)); return; }
-  const ScPts v = sc_points(t.lo, t.hi); P.p2 = v.v2; P.p3 = v.v3;
+  const ScPts v = KIND == KIND_CUBIC ? sc_points_u(t.lo, t.hi) : sc_points(t.lo, t.hi); P.p2 = v.v2; P.p3 = v.v3;
 }
 template <int KIND> __device__ __forceinline__ void sc_times(ScProd& P, const ScPair& t) {
+  if (KIND == KIND_CUBIC) {                      // A*B*C: everything non-negative (see sc_points_u)
+    const ScPts v = sc_points_u(t.lo, t.hi);
+    P.p0 = fe_mulu(P.p0, t.lo); P.p2 = fe_mulu(P.p2, v.v2); P.p3 = fe_mulu(P.p3, v.v3);
+    return;
+  }
   P.p0 = fe_mul(P.p0, t.lo);
   if (KIND == KIND_QUAD) { P.p2 = fe_mul(P.p2, fe_norm(fe_sub_lazy(fe_dbl_lazy(t.hi), t.lo))); return; }
   const ScPts v = sc_points(t.lo, t.hi); P.p2 = fe_mul(P.p2, v.v2); P.p3 = fe_mul(P.p3, v.v3);
@@ -234,7 +266,7 @@ __global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __
     fr_acc(e0, P.p0, c0); fr_acc(e2, P.p2, c2);
     if (KIND != KIND_QUAD) fr_acc(e3, P.p3, c3);
   }
-  sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial);
+  if (sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, tickets ? out : nullptr, seq)) return;
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
@@ -328,7 +360,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* _
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3);   // "par" instance: the shared C arrives bound
   else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3);
-  sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial);
+  sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, nullptr, 0u);
 }
 
 // out-of-place bind of the top variable of ONE table: dst[i] = Z[i] + r (Z[i + half] - Z[i]), i < half.  Runs ahead of a fused

@@ -5,12 +5,12 @@
 
 Extracts the gfx950 code object from the .so (llvm-objdump --offloading), reads the kernel descriptors' metadata
 (llvm-readelf --notes: VGPRs, SGPRs, scratch, LDS) and disassembles it (llvm-objdump -d --mcpu=gfx950), then counts per kernel:
-  v_mad_u64_u32   the only wide multiplier of the CDNA4 VALU (4.8 cycles per wave-instruction measured, tools/micro/ubench.hip)
-  v_mul_lo_u32    the Montgomery quotient digits
-  other VALU      carry captures, add/sub chains, selects, moves (2 cycles each with >= 2 waves per SIMD)
+  v_mad_u64_u32   (+ v_mad_i64_i32) the only wide multiplier of the CDNA4 VALU: 4.2 cycles per wave-instruction (tools/micro/ibench.hip)
+  v_mul_lo_u32    the Montgomery quotient digits (4.2)
+  other VALU      shifts, masks, limb additions, selects, moves: 2.3 cycles for plain VOP2 forms, 4.2 for VOP3 / 64-bit / carry forms
   s_nop, SALU, VMEM (global/buffer/scratch), LDS, waitcnt
-and prices them: cycles ~ 4.8 * (mad + mul_lo) + 2 * other VALU; `mult_share` = the multiplier's part of that (1.0 = nothing but
-products).  Needs no GPU (runs on the build machine)."""
+and prices them roughly: cycles ~ 4.2 * (mad + mul_lo) + 3 * other VALU; `mult_share` = the multiplier's part of that (1.0 = nothing
+but products).  Needs no GPU (runs on the build machine)."""
 import argparse
 import json
 import os
@@ -22,7 +22,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MAD_CYC, VALU_CYC = 4.8, 2.0
+MAD_CYC, VALU_CYC = 4.2, 3.0
 
 
 def extract(so):
@@ -92,7 +92,7 @@ def disasm_counts(co):
             continue
         c = counts[cur]
         c["total"] += 1
-        if op == "v_mad_u64_u32":
+        if op in ("v_mad_u64_u32", "v_mad_i64_i32"):          # the wide multiplier, unsigned and signed form
             c["v_mad_u64_u32"] += 1
         elif op == "v_mul_lo_u32":
             c["v_mul_lo_u32"] += 1
@@ -151,7 +151,7 @@ def main():
         rows.append({"kernel": short, "vgpr": m.get("vgpr_count"), "agpr": m.get("agpr_count", 0), "sgpr": m.get("sgpr_count"), "scratch_B": m.get("private_segment_fixed_size"),
                      "lds_B": m.get("group_segment_fixed_size"), "waves_per_simd": waves_per_simd((m.get("vgpr_count") or 0) + (m.get("agpr_count") or 0)),
                      **c, "mult_share": round(cyc_mult / (cyc_mult + cyc_other), 3) if (cyc_mult + cyc_other) else None,
-                     "products_equiv": round(c["v_mad_u64_u32"] / 128.0, 1)})
+                     "products_equiv": round(c["v_mad_u64_u32"] / 162.0, 1)})
     hdr = f"{'kernel':44s} {'vgpr':>4s} {'w/S':>3s} {'scr':>4s} {'instr':>6s} {'mad64':>6s} {'mullo':>5s} {'oVALU':>6s} {'s_nop':>5s} {'vmem':>4s} {'lds':>4s} {'mult%':>6s}"
     print(hdr)
     for r in rows:
