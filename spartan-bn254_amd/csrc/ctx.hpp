@@ -20,6 +20,9 @@ struct sbn_ctx {
   hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
   hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
   DevBuf zstage[2], out_rows, comb_partial;
+  DevBuf s2_cnt, s2_part, s2_idx, s2_lo;     // two-level sort of a large single MSM (sort2_kernels.cuh)
+  bool sort2_ok = false;      // dynamic LDS of its level-1 scatter granted
+  size_t sort2_min = (size_t)1 << 20;   // terms from which a single MSM takes the two-level sort (SBN_SORT2_MIN; 0 = never)
   int sc_waves = 2;           // streaming sumcheck rounds: 2 = software-pipelined loads, 2 waves per SIMD (default); 3 / 4 = the plain kernel at that occupancy (SBN_SC_WAVES)
   bool sort_rows_ok = false;  // 160 KiB dynamic LDS granted to k_sort_rows
   int sort_rs_max = 16384;   // LDS counters per sort block (raised to 32768 when 128 KiB of dynamic LDS is granted)

@@ -19,10 +19,11 @@ static MsmShape make_shape(int c) {
 // SBN_MSM_C overrides for experiments.
 // Small jobs (`problems` x `terms` far below the chip's lane count) are latency-bound: what counts is the length of the longest
 // bucket chain, not the number of products, so they take the smallest window with a mean bucket load <= 4.
-static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, size_t problems = 0) {
+// `chard`: the widest window the caller's sort can take (MSM_C_MAX for the one-level LDS sort, S2_C_MAX for the two-level one).
+static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, size_t problems = 0, int chard = MSM_C_MAX) {
   const char* env = getenv("SBN_MSM_C");
-  if (env && atoi(env) >= 7 && atoi(env) <= MSM_C_MAX) return make_shape(atoi(env));
-  if (cmax > MSM_C_MAX) cmax = MSM_C_MAX;
+  if (env && atoi(env) >= 7 && atoi(env) <= chard) return make_shape(atoi(env));
+  if (cmax > chard) cmax = chard;
   if (problems && problems * terms <= 32768) {
     // expected longest chain ~ mean load + the load of the top window's few buckets (it holds only 254 - (W-1)c bits)
     double bl = 1e300; int bcl = 7;
@@ -38,15 +39,90 @@ static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, siz
   }
   double best = 1e300; int bc = 7;
   // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
-  // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows.
-  if (cmax > MSM_C_MAX) cmax = MSM_C_MAX;
+  // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows;
+  // the two-level sort (sort2_kernels.cuh) has no such cap and lets large single MSMs take c up to 22.
   for (int c = 7; c <= cmax; c++) {
     MsmShape s = make_shape(c);
     double sets = shared_bucket_set ? 1.0 : (double)s.W;
-    double cost = (double)terms * s.W * 10.0 + sets * s.nb * 56.0;
+    // per bucket: ~56 products in the one-level regime (measured at 2^20), ~40 once the reduction runs on millions of buckets
+    double cost = (double)terms * s.W * 10.0 + sets * s.nb * (chard > MSM_C_MAX ? 40.0 : 56.0);
+    // a top window narrower than c - 1 bits fills only 2^tb of its buckets, each 2^(c-1-tb) times over: those go through the
+    // segment work list (k_acc_extra / k_acc_merge), measured at about half a window's worth of additions on top
+    if (!shared_bucket_set && 254 - (s.W - 1) * c < c - 1) cost += (double)terms * 5.0;
     if (cost < best) { best = cost; bc = c; }
   }
   return make_shape(bc);
+}
+
+// ---- two-level sort of a large single MSM (sort2_kernels.cuh) ----
+#define S2_FOR_EACH_C(X) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22)
+static bool sort2_set_lds() {
+  bool ok = true;
+  const int bytes = (int)s2_scatter_lds_bytes(S2_P_MAX);
+  if (hipFuncSetAttribute((const void*)k_s2_place<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_place_lds_bytes<8>(S2_LO_LOG_MAX)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  if (hipFuncSetAttribute((const void*)k_s2_place<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_place_lds_bytes<16>(S2_LO_LOG_MAX)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+#define X(C) if (hipFuncSetAttribute((const void*)k_s2_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  S2_FOR_EACH_C(X)
+#undef X
+  return ok;
+}
+static bool sort2_applies(const sbn_ctx* c, int mode, size_t n, int cbits) {
+  return mode == MODE_SINGLE && c->sort2_ok && c->sort2_min && n >= c->sort2_min && cbits >= S2_C_MIN && cbits <= S2_C_MAX;
+}
+// scalars -> hist / offs / sorted of all W windows (the arrays the one-level sort leaves behind)
+static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmShape& s, size_t estride, uint32_t* hist, uint32_t* offs, uint32_t* sorted) {
+  S2Geom g; g.n = n; g.c = s.c; g.W = s.W;
+  // bucket index = hi (level 1, <= 1024 partitions) | lo (level 2, <= 2048 LDS counters): runs of 8192 / P entries leave level 1,
+  // runs of tile / 2^lo_log leave level 2
+  g.lo_log = std::max(s.c - 1 - 8, 8); if (g.lo_log > S2_LO_LOG_MAX) g.lo_log = S2_LO_LOG_MAX;
+  if (const char* e = getenv("SBN_SORT2_LO")) { int v = atoi(e); if (v >= 4 && v <= S2_LO_LOG_MAX) g.lo_log = v; }
+  if (s.c - 1 - g.lo_log < 0) g.lo_log = s.c - 1;
+  while ((s.nb >> g.lo_log) > S2_P_MAX) g.lo_log++;
+  if (g.lo_log > S2_LO_LOG_MAX) return fail(c, SBN_EINVAL, "two-level sort: window of %d bits is too wide", s.c);
+  g.P = s.nb >> g.lo_log;
+  const int LO = 1 << g.lo_log;
+  g.K = (int)((n + S2_CH - 1) / S2_CH);
+  const size_t WP = (size_t)g.W * g.P;
+  const size_t max_sc = ((size_t)g.W * n) / S2_SUB + WP;          // sum over partitions of ceil(cnt / S2_SUB), cnt summing to <= W n
+  int rc;
+  if ((rc = ensure(c, c->s2_cnt, WP * g.K * 4))) return rc;
+  if ((rc = ensure(c, c->s2_part, (3 * WP + 1) * 4))) return rc;
+  if ((rc = ensure(c, c->s2_idx, (size_t)g.W * n * 4))) return rc;
+  if ((rc = ensure(c, c->s2_lo, (size_t)g.W * n * 2))) return rc;
+  if ((rc = ensure(c, c->blockhist, max_sc * LO * 4))) return rc;
+  uint32_t* cntA = (uint32_t*)c->s2_cnt.p; uint32_t* part_cnt = (uint32_t*)c->s2_part.p; uint32_t* part_off = part_cnt + WP; uint32_t* sc_off = part_off + WP;
+  uint32_t* tmp_idx = (uint32_t*)c->s2_idx.p; uint16_t* tmp_lo = (uint16_t*)c->s2_lo.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
+  const size_t lds_a = WP * 4, lds_c = s2_scatter_lds_bytes(g.P);
+  {
+    ProfScope _ps(c, "k_s2_count");
+    switch (s.c) {
+#define X(C) case C: hipLaunchKernelGGL(k_s2_count<C>, dim3(g.K), dim3(1024), lds_a, c->stream, scalars, g, cntA, c->d_bad); break;
+      S2_FOR_EACH_C(X)
+#undef X
+    }
+  }
+  LAUNCH(c, "k_s2_prefix", k_s2_prefix_k, (unsigned)WP, 256, cntA, g.K, part_cnt);
+  LAUNCH(c, "k_s2_prefix", k_s2_prefix_hi, 1, 1024, (const uint32_t*)part_cnt, g.W, g.P, part_off, sc_off);
+  {
+    ProfScope _ps(c, "k_s2_scatter");
+    switch (s.c) {
+#define X(C) case C: hipLaunchKernelGGL(k_s2_scatter<C>, dim3(g.K), dim3(1024), lds_c, c->stream, scalars, g, (const uint32_t*)cntA, (const uint32_t*)part_off, tmp_idx, tmp_lo); break;
+      S2_FOR_EACH_C(X)
+#undef X
+    }
+  }
+  const unsigned l2 = s2_level2_blocks(max_sc);
+  LAUNCH(c, "k_s2_hist", k_s2_hist, l2, 1024, (const uint16_t*)tmp_lo, g, (const uint32_t*)part_off, (const uint32_t*)part_cnt, (const uint32_t*)sc_off, bh);
+  LAUNCH(c, "k_s2_prefix", k_s2_prefix2, (unsigned)WP, 1024, bh, g, (const uint32_t*)part_off, (const uint32_t*)sc_off, hist, offs);
+  {
+    ProfScope _ps(c, "k_s2_place");
+    int ept = 8; if (const char* e = getenv("SBN_SORT2_EPT")) { if (atoi(e) == 16) ept = 16; }
+#define S2_PLACE_ARGS (const uint16_t*)tmp_lo, (const uint32_t*)tmp_idx, g, (const uint32_t*)part_off, (const uint32_t*)part_cnt, (const uint32_t*)sc_off, (const uint32_t*)bh, (const uint32_t*)offs, sorted, estride
+    if (ept == 16) hipLaunchKernelGGL(k_s2_place<16>, dim3(l2), dim3(1024), s2_place_lds_bytes<16>(g.lo_log), c->stream, S2_PLACE_ARGS);
+    else hipLaunchKernelGGL(k_s2_place<8>, dim3(l2), dim3(1024), s2_place_lds_bytes<8>(g.lo_log), c->stream, S2_PLACE_ARGS);
+#undef S2_PLACE_ARGS
+  }
+  return SBN_OK;
 }
 
 struct BucketJob {
@@ -109,6 +185,12 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   g.R = s.nb / g.RS;
   { size_t want = (1024 + J.P * g.R - 1) / (J.P * g.R); size_t maxk = std::max<size_t>(1, estride / 4096); g.K = (int)std::max<size_t>(1, std::min(want, maxk)); }
   g.chunk = (estride + g.K - 1) / g.K;
+  const uint8_t* skip = nullptr;
+  const bool two_level = sort2_applies(c, J.mode, J.da.n, s.c) && !J.skip;
+  if (s.c > MSM_C_MAX && !two_level) return fail(c, SBN_EINVAL, "window of %d bits needs the two-level sort", s.c);
+  if (two_level) {
+    if ((rc = sort2_run(c, J.da.scalars, J.da.n, s, estride, hist, offs, sorted))) return rc;
+  } else {
   if (J.P > 65535 || g.R > 65535) return fail(c, SBN_EINVAL, "sort grid too large (P=%zu R=%d)", J.P, g.R);
   if ((rc = ensure(c, c->digits, J.P * estride * sizeof(dig_t)))) return rc;
   if ((rc = ensure(c, c->blockhist, J.P * (size_t)g.R * g.K * g.RS * 4))) return rc;
@@ -116,7 +198,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   const unsigned gd = (unsigned)((J.threads + 255) / 256);
   const size_t rows_lds = sort_rows_lds_bytes(s.nb);
   const bool fused_rows = J.mode == MODE_ROWS && c->sort_rows_ok && rows_lds <= 160 * 1024 && estride <= 8 * (size_t)SORT_SL && !getenv("SBN_NO_FUSED_SORT");
-  const uint8_t* skip = fused_rows ? J.skip : nullptr;    // the generic sort reads every digit, so nothing may be left unwritten there
+  skip = fused_rows ? J.skip : nullptr;    // the generic sort reads every digit, so nothing may be left unwritten there
   if (J.mode == MODE_SINGLE) LAUNCH(c, "k_digits_store", (k_digits_store<MODE_SINGLE>), gd, 256, J.da, s, dig, (const uint8_t*)nullptr);
   else LAUNCH(c, "k_digits_store", (k_digits_store<MODE_ROWS>), gd, 256, J.da, s, dig, skip);
   if (c->z_consumed && J.mode == MODE_ROWS) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));   // the scalars are not read again
@@ -135,6 +217,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
       hipLaunchKernelGGL(k_scatter_lds, dim3(g.K, g.R, (unsigned)J.P), dim3(1024), (size_t)g.RS * 4, c->stream, (const dig_t*)dig, g, (const uint32_t*)bh, (const uint32_t*)offs, sorted);
     }
   }
+  }   // one-level sort
   // bucket order by decreasing load
   if ((rc = ensure(c, c->size_bins, (ACC_SEG_MAX + 2) * 4))) return rc;
   if ((rc = ensure(c, c->perm, NB * 4))) return rc;
@@ -171,7 +254,13 @@ static int msm_device(sbn_ctx* c, const uint32_t* d_scal, const uint32_t* d_base
   if (n == 0) { memset(out_xy, 0, 64); if (out_is_inf) *out_is_inf = 1; return SBN_OK; }
   if (n > 0x7fffffffull) return fail(c, SBN_EINVAL, "msm: n=%zu exceeds 2^31-1", n);
   BucketJob J; memset(&J, 0, sizeof J);
-  J.mode = MODE_SINGLE; { int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++; J.s = choose_shape(n, false, cm + 1, 1); } J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
+  J.mode = MODE_SINGLE;
+  {
+    int cm = 1; while ((1 << cm) < c->sort_rs_max) cm++;
+    const bool s2 = sort2_applies(c, MODE_SINGLE, n, S2_C_MIN);
+    J.s = choose_shape(n, false, s2 ? S2_C_MAX : cm + 1, 1, s2 ? S2_C_MAX : MSM_C_MAX);
+  }
+  J.P = (size_t)J.s.W; J.threads = n; J.points = d_bases;
   J.da.scalars = d_scal; J.da.n = n; J.da.estride = n; J.da.bad = c->d_bad;
   int rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, J.P * 128)))) return rc;

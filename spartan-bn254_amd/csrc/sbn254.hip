@@ -9,6 +9,7 @@
 #include "../../include/sbn254.h"
 #include "host_field.hpp"
 #include "msm_kernels.cuh"
+#include "sort2_kernels.cuh"
 #include "comb_kernels.cuh"
 #include "sumcheck_kernels.cuh"
 #include "host_keccak.hpp"

@@ -758,3 +758,51 @@ def test_encode_time_commitment_shapes(ctx, ol, L, R, rows):
         assert out2 == out and infs2 == infs
     finally:
         bases.free()
+
+
+@pytest.fixture()
+def ctx_sort2(sbn, monkeypatch):
+    """a context whose single MSMs take the two-level sort (sort2_kernels.cuh) from 1024 terms on instead of from 2^21"""
+    monkeypatch.setenv("SBN_SORT2_MIN", "1024")
+    c = sbn.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("c_bits,n", [(13, 1024), (13, 9000), (16, 8192), (17, 8193), (19, 20000), (20, 30011), (22, 5000)])
+def test_two_level_sort_vs_oracle(ctx_sort2, ol, pr, monkeypatch, c_bits, n):
+    """the large-MSM sort path at small sizes, every window width it is built for (2 .. 1024 partitions per window; chunks of 8192
+    scalars: one partial chunk, exactly one, one + 1, several): bit-exact vs the discrete-log identity and the CPU Pippenger"""
+    monkeypatch.setenv("SBN_MSM_C", str(c_bits))
+    sc = rand_scalars(n, 900 + n + c_bits)
+    pts, dl = tiled_bases(ol, n, min(n, 4096), 5 + n)
+    out, inf = ctx_sort2.msm(sc, pts)
+    assert ctx_sort2.prof_last_job()["c"] == c_bits                  # the window asked for was the window used
+    assert out == expect_from_dlogs(ol, pr, sc, dl) and not inf
+    if n <= 9000:
+        assert out == ol.msm_pippenger(sc, pts, 8)
+
+
+def test_two_level_sort_skew_and_edges(ctx_sort2, ol, pr, sbn, monkeypatch):
+    """skewed scalars (one partition of one window holds everything), zero scalars, r - 1, powers of two at the window seams, and
+    a non-canonical scalar (rejected, scalar.rs:87-95) on the two-level path"""
+    monkeypatch.setenv("SBN_MSM_C", "18")
+    n = 12000
+    pts, dl = tiled_bases(ol, n, 2048, 11)
+    vals = [7] * 6000 + [0] * 1000 + [pr.R - 1] * 1000 + [1 << (18 * (i % 14)) for i in range(1000)] + [(1 << (18 * (i % 14) + 17)) for i in range(1000)] + [(1 << (18 * (i % 13) + 18)) - 1 for i in range(2000)]
+    sc = b"".join(pr.scalar_to_bytes(v % pr.R) for v in vals)
+    out, inf = ctx_sort2.msm(sc, pts)
+    assert out == expect_from_dlogs(ol, pr, sc, dl)
+    bad = bytearray(sc); bad[32 * 5000:32 * 5000 + 32] = pr.R.to_bytes(32, "little")
+    with pytest.raises(sbn.SbnError):
+        ctx_sort2.msm(bytes(bad), pts)
+    assert ctx_sort2.msm(sc, pts)[0] == out                          # and the context is usable afterwards
+
+
+def test_two_level_sort_matches_one_level(ctx, ctx_sort2, ol, monkeypatch):
+    """same inputs, same window: both sorts feed the same accumulation -> identical bytes (2^17 terms, c = 15 and c = 16)"""
+    n = 1 << 17
+    sc = rand_scalars(n, 4242); pts, _ = tiled_bases(ol, n, 4096, 4243)
+    for c_bits in (15, 16):
+        monkeypatch.setenv("SBN_MSM_C", str(c_bits))
+        assert ctx.msm(sc, pts) == ctx_sort2.msm(sc, pts)

@@ -123,6 +123,27 @@ template <int T> __global__ void __launch_bounds__(256) k_inst(uint32_t* o, cons
       R16(X)
 #undef X
       "s_nop 0" : OPS32 : "v"(x));
+    // dependent chains: the same accumulator every D-th instruction (D = 1, 2, 4) — what a column sum of products looks like
+    if (T == 20) asm volatile(
+#define X(i) "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+      R16(X)
+#undef X
+      "s_nop 0" : OPS64 : "v"(x), "v"(y) : "vcc");
+    if (T == 21) asm volatile(
+#define X(i) "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\t"
+      X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
+      "s_nop 0" : OPS64 : "v"(x), "v"(y) : "vcc");
+    if (T == 22) asm volatile(
+#define X(i) "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\t"
+      X(0) X(1) X(2) X(3)
+#undef X
+      "s_nop 0" : OPS64 : "v"(x), "v"(y) : "vcc");
+    if (T == 23) asm volatile(    // the carry step between two columns: shift, then add (dependent pair, 8 times)
+#define X(i) "v_lshrrev_b64 %0, 29, %0\n\tv_lshl_add_u64 %0, %1, 0, %0\n\t"
+      X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#undef X
+      "s_nop 0" : OPS64 : "v"(x), "v"(y) : "vcc");
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
   uint32_t acc = 0;
@@ -174,6 +195,10 @@ int main() {
   run<15>("v_mul_hi_u32", d_o, d_in, d_clk);
   run<16>("v_mad_u32_u24", d_o, d_in, d_clk);
   run<19>("v_mul_u32_u24", d_o, d_in, d_clk);
+  run<20>("v_mad_u64_u32 chain distance 1", d_o, d_in, d_clk);
+  run<21>("v_mad_u64_u32 chain distance 2", d_o, d_in, d_clk);
+  run<22>("v_mad_u64_u32 chain distance 4", d_o, d_in, d_clk);
+  run<23>("shift+add dependent pair chain", d_o, d_in, d_clk);
   run<9>("v_lshl_add_u64 (64-bit add)", d_o, d_in, d_clk);
   run<10>("v_lshrrev_b64", d_o, d_in, d_clk);
   run<11>("v_and_b32", d_o, d_in, d_clk);
