@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--sc-log-n", type=int, default=21, help="sumcheck block: log2 of the table length")
     ap.add_argument("--const-tail", type=float, default=0.0, help="hyrax: fraction of each 512-row block whose rows repeat one constant "
                     "(the padded tail of every derefs matrix repeats mem[0], sparse_mlpoly_full.rs:89-101; ~0.43 at keyless size)")
-    ap.add_argument("--precompute-gb", type=float, default=100.0, help="hyrax: HBM budget (GiB) of the fixed-base lookup table of the generator set "
+    ap.add_argument("--precompute-gb", type=float, default=200.0, help="hyrax: HBM budget (GiB) of the fixed-base lookup table of the generator set "
                     "(sbn_bases_precompute; built once before the timed region like any commitment-key setup); 0 = bucket method only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

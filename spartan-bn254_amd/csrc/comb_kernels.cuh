@@ -13,6 +13,7 @@
 namespace sbn {
 
 constexpr int COMB_CH = 64;      // multiples per lane in the table build (one batched inversion per lane)
+constexpr int COMB_C_MAX = 17;   // widest lookup window (c = 17: 15 windows; 177 GB for the 2814 unique points of the 8193-generator set)
 
 // One window slab of the table.  Lane t -> (column j, chunk a): entries d = 64 a + 1 .. 64 a + 64 of column j.
 // tmp_xyzz / tmp_pref: COMB_CH x lanes records (k-major, so a wave's accesses are contiguous).
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
   // Q = (64 a) * P, then 64 mixed additions
   XYZZ Q = xyzz_inf();
   const uint32_t m0 = (uint32_t)(a * COMB_CH);
-  for (int b = 15; b >= 0; b--) {
+  for (int b = COMB_C_MAX - 1; b >= 0; b--) {
     Q = xyzz_dbl(Q);
     if ((m0 >> b) & 1u) xyzz_madd(Q, P, false);
   }
@@ -107,7 +108,7 @@ __global__ void __launch_bounds__(64) k_comb_rows_const(const uint32_t* __restri
       xyzz_madd(acc, aff_load(table + 16 * ti), d < 0);
     }
   }
-  acc = wave_sum(acc, lane);
+  acc = wave_sum_all(acc);
   if (lane == 0) xyzz_store(sparse + 32 * row, acc);
 }
 // Few rows (bullet rounds, single commits): the (window, column) pairs of a row are dealt out one by one over S*256 lanes, so
@@ -134,34 +135,20 @@ __global__ void __launch_bounds__(256) k_comb_rows_flat(const uint32_t* __restri
     if (have) xyzz_madd(acc, p_prev, neg_prev);
   }
   __shared__ uint32_t sm[4][32];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  acc = wave_sum(acc, lane);
-  if (lane == 0) xyzz_store(sm[wv], acc);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    XYZZ t = xyzz_load(sm[0]);
-    for (int w = 1; w < 4; w++) t = xyzz_add(t, xyzz_load(sm[w]));
-    xyzz_store(partial + 32 * (row * S + blockIdx.y), t);
-  }
+  const XYZZ t = block_sum_quad(acc, sm);                 // log-depth, quad-cooperative additions (g1.cuh)
+  if (threadIdx.x == 0) xyzz_store(partial + 32 * (row * S + blockIdx.y), t);
 }
 // per row: `per_row` lane accumulators -> out[row].  One block per row: strided partial sums, wave tree, and — when the block has
 // four waves (many accumulators per row, i.e. few rows) — an LDS step across them.  Many rows use one wave per row.
 // Rows with flags[row] != 0 take the point k_comb_rows_const left in sparse[row].
 __global__ void __launch_bounds__(256) k_comb_fold(const uint32_t* __restrict__ partial, unsigned per_row, uint32_t* __restrict__ out, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ sparse) {
-  const size_t row = blockIdx.x; const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t row = blockIdx.x;
   __shared__ uint32_t sm[4][32];
   if (flags && flags[row] != 0) { if (threadIdx.x == 0) xyzz_store(out + 32 * row, xyzz_load(sparse + 32 * row)); return; }
   XYZZ v = xyzz_inf();
   for (unsigned i = threadIdx.x; i < per_row; i += blockDim.x) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
-  v = wave_sum(v, lane);
-  if (blockDim.x == 64) { if (lane == 0) xyzz_store(out + 32 * row, v); return; }
-  if (lane == 0) xyzz_store(sm[wv], v);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    XYZZ t = xyzz_load(sm[0]);
-    for (int w = 1; w < 4; w++) t = xyzz_add(t, xyzz_load(sm[w]));
-    xyzz_store(out + 32 * row, t);
-  }
+  v = block_sum_quad(v, sm);
+  if (threadIdx.x == 0) xyzz_store(out + 32 * row, v);
 }
 
 }  // namespace sbn

@@ -386,4 +386,23 @@ template <class M> __device__ __forceinline__ Fe<M> fe_shfl_xor(const Fe<M>& a, 
   for (int i = 0; i < NL; i++) r.v[i] = __shfl_xor(a.v[i], mask, 64);
   return r; }
 
+// ---- quad helpers (latency-bound sums, g1.cuh: xyzz_add_quad): lanes 4q .. 4q+3 work on one addition ----
+// value of lane K of the caller's quad, in all four lanes (DPP quad_perm: no LDS, no waitcnt)
+template <int K, class M> __device__ __forceinline__ Fe<M> fe_quad_bcast(const Fe<M>& a) { Fe<M> r;
+#pragma unroll
+  // (update_dpp with old = src; __builtin_amdgcn_mov_dpp with bound_ctrl gave wrong values in two lanes of every quad once the
+  //  compiler folded it into the consuming instruction — measured with tools/micro/g1test.hip)
+  for (int i = 0; i < NL; i++) r.v[i] = (uint32_t)__builtin_amdgcn_update_dpp((int)a.v[i], (int)a.v[i], K * 0x55, 0xf, 0xf, false);
+  return r; }
+// role-indexed operand: role 0..3 picks a0..a3 (limb-wise selects; the four values need not be normalised alike)
+template <class M> __device__ __forceinline__ Fe<M> fe_sel4(int role, const Fe<M>& a0, const Fe<M>& a1, const Fe<M>& a2, const Fe<M>& a3) { Fe<M> r;
+  const bool hi = (role & 2) != 0, odd = (role & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) { const uint32_t lo2 = odd ? a1.v[i] : a0.v[i], hi2 = odd ? a3.v[i] : a2.v[i]; r.v[i] = hi ? hi2 : lo2; }
+  return r; }
+template <class M> __device__ __forceinline__ Fe<M> fe_sel2(bool second, const Fe<M>& a0, const Fe<M>& a1) { Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < NL; i++) r.v[i] = second ? a1.v[i] : a0.v[i];
+  return r; }
+
 }  // namespace sbn

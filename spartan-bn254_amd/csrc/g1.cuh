@@ -141,4 +141,75 @@ __device__ __forceinline__ XYZZ xyzz_shfl_xor(const XYZZ& p, int mask) {
   return r;
 }
 
+// ---- latency-shaped addition: the four lanes of a quad compute ONE a + b -----------------------------------------------------
+// A tree sum on a few waves is a chain of dependent field products (0.54 us each on a lone wave: 7.6 us per full addition),
+// while 3 of every 4 lanes sit idle from the second tree level on.  Here every lane of a quad holds both operands, each of the
+// four product steps computes up to four DIFFERENT products of the formula (one per lane, operands picked by the lane's role),
+// and the results are broadcast inside the quad (DPP): 4 dependent products instead of 14.  All four lanes return the sum.
+// Same formula, same operand ranges and the same degenerate cases as xyzz_add_inl.  `role` = lane & 3.
+// (force-inlined: an out-of-line copy would take its operands through scratch memory; block_sum_quad below has ONE call site)
+__device__ __forceinline__ XYZZ xyzz_add_quad(const XYZZ& a, const XYZZ& b, int role) {
+  if (xyzz_is_inf(a)) return b;                  // (uniform inside the quad: its lanes hold the same a, b)
+  if (xyzz_is_inf(b)) return a;
+  // step 1: U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+  const Fq t1 = fe_mulu(fe_sel4(role, a.X, b.X, a.Y, b.Y), fe_sel4(role, b.ZZ, a.ZZ, b.ZZZ, a.ZZZ));
+  const Fq U1 = fe_quad_bcast<0>(t1), U2 = fe_quad_bcast<1>(t1), S1 = fe_quad_bcast<2>(t1), S2 = fe_quad_bcast<3>(t1);
+  const Fq P = fe_normu(fe_subb<FqP, 2, 1>(U2, U1)), R = fe_normu(fe_subb<FqP, 2, 1>(S2, S1));
+  if (fe_maybe_zero(P) && fe_is_zero(P)) {
+    if (fe_is_zero(R)) return xyzz_dbl(a);
+    return xyzz_inf();
+  }
+  // step 2: PP = P P | RR = R R | Z12 = ZZ1 ZZ2 | Z123 = ZZZ1 ZZZ2   (the last two stay with their lanes)
+  const Fq t2 = fe_mulu(fe_sel4(role, P, R, a.ZZ, a.ZZZ), fe_sel4(role, P, R, b.ZZ, b.ZZZ));
+  const Fq PP = fe_quad_bcast<0>(t2), RR = fe_quad_bcast<1>(t2);
+  // step 3: PPP = P PP | Q = U1 PP | ZZ3 = Z12 PP | (lane 3: a spare P PP)
+  const Fq t3 = fe_mulu(fe_sel4(role, P, U1, t2, P), PP);
+  const Fq PPP = fe_quad_bcast<0>(t3), Q = fe_quad_bcast<1>(t3);
+  XYZZ r;
+  r.ZZ = fe_quad_bcast<2>(t3);
+  r.X = fe_normu(fe_subb<FqP, 4, 3>(RR, fe_add_lazy(fe_add_lazy(PPP, Q), Q)));
+  // step 4: T1 = R (Q - X3) | T2 = S1 PPP | (lane 2: a spare) | ZZZ3 = Z123 PPP
+  const Fq t4 = fe_mulu(fe_sel4(role, R, S1, S1, t2), fe_sel2(role == 0, PPP, fe_subb<FqP, 6, 1>(Q, r.X)));
+  r.Y = fe_normu(fe_subb<FqP, 2, 1>(fe_quad_bcast<0>(t4), fe_quad_bcast<1>(t4)));
+  r.ZZZ = fe_quad_bcast<3>(t4);
+  return r;
+}
+template <int K> __device__ __forceinline__ XYZZ xyzz_quad_bcast(const XYZZ& p) {
+  XYZZ r; r.X = fe_quad_bcast<K>(p.X); r.Y = fe_quad_bcast<K>(p.Y); r.ZZ = fe_quad_bcast<K>(p.ZZ); r.ZZZ = fe_quad_bcast<K>(p.ZZZ); return r;
+}
+// the two operands of a butterfly step at distance d, in the same order in both groups (lower group's value first)
+__device__ __forceinline__ void xyzz_butterfly_operands(const XYZZ& v, int d, int lane, XYZZ& a, XYZZ& b) {
+  const XYZZ o = xyzz_shfl_xor(v, d);
+  const bool up = (lane & d) != 0;
+  a.X = fe_sel2(up, v.X, o.X); a.Y = fe_sel2(up, v.Y, o.Y); a.ZZ = fe_sel2(up, v.ZZ, o.ZZ); a.ZZZ = fe_sel2(up, v.ZZZ, o.ZZZ);
+  b.X = fe_sel2(up, o.X, v.X); b.Y = fe_sel2(up, o.Y, v.Y); b.ZZ = fe_sel2(up, o.ZZ, v.ZZ); b.ZZZ = fe_sel2(up, o.ZZZ, v.ZZZ);
+}
+// Sum over a block of 64 .. 256 lanes, returned in lanes 0..3 of wave 0 (with one wave: in every lane).  sm: 4 x 128 B of LDS.
+// 7 quad additions per wave — a quad first adds its own four points (p0 + p1, p2 + p3, then the two sums: every lane gets all
+// four by DPP), then quads pair up by butterfly exchange — and 1 or 2 more across the waves (quad q of wave 0 adds the totals of
+// waves 2q and 2q + 1 from LDS, then the two quads add each other's result).  ONE loop with ONE inlined addition: these kernels
+// run each instruction once, so their size is instruction-fetch time.
+__device__ __forceinline__ XYZZ block_sum_quad(const XYZZ& v, uint32_t (*sm)[32]) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6), role = lane & 3;
+  const int nsteps = 7 + (nw > 1 ? 1 : 0) + (nw > 2 ? 1 : 0);
+  XYZZ keep = v, cur = v;
+#pragma unroll 1
+  for (int step = 0; step < nsteps; step++) {
+    XYZZ a, b;
+    if (step == 0) { a = xyzz_quad_bcast<0>(keep); b = xyzz_quad_bcast<1>(keep); }
+    else if (step == 1) { a = xyzz_quad_bcast<2>(keep); b = xyzz_quad_bcast<3>(keep); keep = cur; }
+    else if (step == 2) { a = keep; b = cur; }
+    else if (step == 7) {
+      if (lane == 0) xyzz_store(sm[wv], cur);
+      __syncthreads();
+      const int q = lane >> 2;
+      a = (2 * q < nw) ? xyzz_load(sm[(2 * q) & 3]) : xyzz_inf(); b = (2 * q + 1 < nw) ? xyzz_load(sm[(2 * q + 1) & 3]) : xyzz_inf();
+    }
+    else xyzz_butterfly_operands(cur, step == 8 ? 4 : (4 << (step - 3)), lane, a, b);
+    cur = xyzz_add_quad(a, b, role);
+  }
+  return cur;
+}
+__device__ __forceinline__ XYZZ wave_sum_all(const XYZZ& v) { return block_sum_quad(v, nullptr); }    // blockDim.x == 64 only
+
 }  // namespace sbn

@@ -303,12 +303,12 @@ static int bases_window_table(sbn_ctx* c, const sbn_bases* b, const MsmShape& s,
   return SBN_OK;
 }
 
-// Direct-lookup table of a generator set (comb_kernels.cuh): the largest window c <= 16 whose table fits `max_bytes`.
+// Direct-lookup table of a generator set (comb_kernels.cuh): the largest window c <= COMB_C_MAX (17) whose table fits `max_bytes`.
 static int bases_build_comb(sbn_ctx* c, sbn_bases* b, size_t max_bytes) {
   const size_t npts = b->n + (b->has_h ? 1 : 0);
   if (npts == 0) return fail(c, SBN_EINVAL, "precompute: empty generator set");
   int cc = 0; size_t bytes = 0;
-  for (int t = MSM_C_MAX; t >= 7; t--) {
+  for (int t = COMB_C_MAX; t >= 7; t--) {
     const MsmShape s = make_shape(t);
     const size_t need = npts * (size_t)s.W * (size_t)s.nb * 64;
     if (need <= max_bytes) { cc = t; bytes = need; break; }
@@ -368,7 +368,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, c->d_bad);
     else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
-    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 64, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
+    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
     RowInfo info; info.flags = rowflags; info.skip_zero = dBl == nullptr;      // with blinds a zero row still commits to blind*h
     info.col_value = U; info.col_blind = (dBl && b->hcol <= U) ? (size_t)b->hcol : ~(size_t)0;
@@ -385,9 +385,14 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     const MsmShape s = make_shape(b->comb_c);
     DigitArgs da; memset(&da, 0, sizeof da);
     da.scalars = dZ; da.blinds = dBl; da.n = ncol; da.R = R; da.L = L; da.tstride = npts; da.bad = c->d_bad;
-    // few rows: spread a row over S blocks so that a lane's chain is ~4 mixed additions (latency-bound regime)
-    unsigned S = 1; while ((size_t)L * S < 2048 && S < 64 && (size_t)S * 1024 < ncol * (size_t)s.W) S <<= 1;
-    if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) S = (unsigned)v; }
+    // few rows (latency-bound regime): spread a row over S blocks so that a lane takes at most two table points — the block
+    // sums are log-depth quad-cooperative additions (3.5 us a level), cheaper than a third chained mixed addition (5.4 us)
+    unsigned S = 1;
+    if ((size_t)L * 64 < 2048 && ncol * (size_t)s.W > 1024) {
+      S = (unsigned)std::min<size_t>(128, (ncol * (size_t)s.W + 511) / 512);
+      while (S > 1 && (size_t)L * S > 4096) S--;
+    }
+    if (const char* es = getenv("SBN_COMB_S")) { int v = atoi(es); if (v >= 1 && v <= 128) S = (unsigned)v; }
     int rc;
     if ((rc = ensure(c, c->wsum, L * 128))) return rc;
     if ((rc = ensure(c, c->comb_partial, S > 1 ? L * S * 128 : L * 257 * 128))) return rc;
@@ -395,7 +400,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     c->last_job[0] = (uint64_t)s.c; c->last_job[1] = (uint64_t)s.W; c->last_job[2] = (uint64_t)(L * ncol * (size_t)s.W); c->last_job[3] = 0;
     if (S > 1) {
       LAUNCH(c, "k_comb_rows", k_comb_rows_flat, dim3((unsigned)L, S), 256, (const uint32_t*)b->d_comb, da, s, skip_rows, (uint32_t*)c->comb_partial.p);
-      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p, (const uint8_t*)nullptr, (const uint32_t*)nullptr);
+      LAUNCH(c, "k_comb_fold", k_comb_fold, (unsigned)L, S > 64 ? 128 : 64, (const uint32_t*)c->comb_partial.p, S, (uint32_t*)c->wsum.p, (const uint8_t*)nullptr, (const uint32_t*)nullptr);
     } else {
       // ordinary rows: one block each; flagged (constant / zero) rows: one wave each over their one or two live columns
       const uint8_t* fl = (ri.flags && ri.col_value != ~(size_t)0) ? ri.flags : nullptr;

@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict_
     if (bi.k <= MERGE_LANE_MAX) continue;
     XYZZ acc = (lane == 0) ? xyzz_load(buckets + 32 * (size_t)bi.bucket * G) : xyzz_inf();
     for (uint32_t j = lane; j < bi.k; j += 64) acc = xyzz_add_inl(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
-    acc = wave_sum(acc, lane);
+    acc = wave_sum_all(acc);
     if (lane == 0) xyzz_store(buckets + 32 * (size_t)bi.bucket * G, acc);
   }
 }
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X
   XYZZ term = (lane >= 1) ? suf : xyzz_inf();      // sum_{l>=1} suf_l = sum_l l*run_l
   term = xyzz_mul_pow2(term, logL);
   term = xyzz_add_inl(term, acc);
-  XYZZ Wt = wave_sum(term, lane);
+  const XYZZ Wt = wave_sum_all(term);              // 7 quad-cooperative additions deep (g1.cuh), every lane gets the sum
   if (lane == 0) { xyzz_store(out + 64 * chunk, S); xyzz_store(out + 64 * chunk + 32, Wt); }
 }
 
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restric
   XYZZ term = (lane >= 1) ? suf : xyzz_inf();
   term = xyzz_mul_pow2(term, logM);
   term = xyzz_add_inl(term, Wt);
-  XYZZ W2 = wave_sum(term, lane);
+  const XYZZ W2 = wave_sum_all(term);
   if (lane == 0) {
     if (final) {
       xyzz_store(out + 32 * prob, xyzz_add_inl(W2, suf));
@@ -628,24 +628,36 @@ __global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict_
   for (uint32_t j = a + 1; j < b; j++) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
   fe_store<FrP>(out + 8 * t, acc);
 }
-// big groups: one wave per (row, big group); constant rows were written by k_merge_small
-__global__ void __launch_bounds__(64) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
-                                                  const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
-                                                  const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
+// big groups: one block per (row, big group), four scalars in flight per lane (a bullet round merges 2 x 5381 scalars: one wave
+// with one load at a time was a chain of 84 exposed load latencies); constant rows were written by k_merge_small
+__global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                                   const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
+                                                   const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
+  __shared__ uint32_t sm[4][NL];
   const size_t row = blockIdx.x / nbig; const uint32_t u = big_list[blockIdx.x % nbig];
   if (flags[row]) return;
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   Fr acc = fe_zero<FrP>();
   uint32_t cnt = 0;
-  for (uint32_t j = a + threadIdx.x; j < b; j += 64) {
-    acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
-    if ((++cnt & 127u) == 0) acc = fe_reduce(acc);                     // lazy values: keep the running sum far below the top limb's range
+  for (uint32_t j = a + threadIdx.x; j < b; j += 1024) {
+    const Fr x0 = merged_load(Z, blinds, row, R, csr_cols[j]);
+    const Fr x1 = j + 256 < b ? merged_load(Z, blinds, row, R, csr_cols[j + 256]) : fe_zero<FrP>();
+    const Fr x2 = j + 512 < b ? merged_load(Z, blinds, row, R, csr_cols[j + 512]) : fe_zero<FrP>();
+    const Fr x3 = j + 768 < b ? merged_load(Z, blinds, row, R, csr_cols[j + 768]) : fe_zero<FrP>();
+    acc = fe_add(fe_add(acc, x0), fe_add(fe_add(x1, x2), x3));
+    if (((cnt += 4) & 127u) == 0) acc = fe_reduce(acc);               // lazy values: keep the running sum far below the top limb's range
   }
   acc = fe_reduce(acc);
-  // wave tree
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) acc = fe_add(acc, fe_shfl_down(acc, d));
-  if (threadIdx.x == 0) fe_store<FrP>(out + 8 * (row * (U + 1) + u), acc);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { for (int k = 0; k < NL; k++) sm[wv][k] = acc.v[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fr s = acc;
+    for (int w = 1; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
+    fe_store<FrP>(out + 8 * (row * (U + 1) + u), s);
+  }
 }
 
 // Jacobian (X, Y, Z) -> Montgomery affine, one lane per point (x = X/Z^2, y = Y/Z^3); canonical input is converted first

@@ -548,7 +548,7 @@ def test_commit_rows_with_lookup_table_vs_oracle(ctx, ol, pr, R, label, budget_m
                 before = ctx.commit_rows(b, Z, bl, L, R)[0]
                 assert before == want_b
                 cw = ctx.bases_precompute(b, budget_mb << 20)
-                assert 7 <= cw <= 16
+                assert 7 <= cw <= 17          # COMB_C_MAX (comb_kernels.cuh)
             assert ctx.commit_rows(b, Z, bl, L, R)[0] == want_b, (L, "blinds")
             out, infs = ctx.commit_rows(b, Z, None, L, R)
             assert out == want_0, (L, "no blinds")
@@ -615,7 +615,7 @@ def test_fuzz_lookup_table_commits(ctx, ol, pr):
         b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
         try:
             cw = ctx.bases_precompute(b, rng.choice([64, 128, 512]) << 20)
-            assert 7 <= cw <= 16
+            assert 7 <= cw <= 17          # COMB_C_MAX (comb_kernels.cuh)
             use_bl = case % 2 == 0
             got, infs = ctx.commit_rows(b, Z, bl if use_bl else None, L, R)
             want = ol.commit_rows(Z, bl if use_bl else None, L, R, gx[:64 * R], gx[64 * R:], 8)

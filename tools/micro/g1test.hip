@@ -27,7 +27,49 @@ __global__ void k_g1(uint32_t* res, uint32_t* scratch) {
     res[4 * k + 3] = (k == 1) ? xyzz_is_inf(m) : aff_same(xyzz_to_affine(m), xyzz_to_affine(p3));
   }
 }
+// block_sum_quad (quad-cooperative additions) against (sum of the lanes' multipliers) * G.  Lane l holds m_l * G, m_l from `pattern`:
+//   0: l + 1 (all distinct)   1: 7 for every lane (every addition is a doubling)   2: +-(l/2 + 1) alternating (every pair cancels)
+//   3: non-zero only in lanes = 5 mod 17 (most operands are the identity)   4: l % 4 + 1 (equal points inside and across quads)
+__device__ XYZZ small_mul(int m) {            // m * G, m may be negative or zero
+  Affine G; G.x = fe_one<FqP>(); G.y = fe_dbl(G.x);
+  XYZZ a = xyzz_inf(); const int am = m < 0 ? -m : m;
+  for (int b = 30; b >= 0; b--) { a = xyzz_dbl(a); if ((am >> b) & 1) xyzz_madd(a, G, m < 0); }
+  return a;
+}
+__device__ int pattern_m(int pattern, int l) {
+  switch (pattern) {
+    case 0: return l + 1;
+    case 1: return 7;
+    case 2: return (l & 1) ? -(l / 2 + 1) : (l / 2 + 1);
+    case 3: return (l % 17 == 5) ? 1000 + l : 0;
+    default: return l % 4 + 1;
+  }
+}
+__global__ void k_quad(uint32_t* res, int pattern) {
+  __shared__ uint32_t sm[4][32];
+  const int l = threadIdx.x;
+  const XYZZ v = small_mul(pattern_m(pattern, l));
+  const XYZZ s = block_sum_quad(v, sm);
+  if (l == 0) {
+    long long tot = 0; for (int i = 0; i < (int)blockDim.x; i++) tot += pattern_m(pattern, i);
+    const XYZZ e = small_mul((int)tot);
+    const bool ok = xyzz_is_inf(e) ? xyzz_is_inf(s) : (!xyzz_is_inf(s) && aff_same(xyzz_to_affine(s), xyzz_to_affine(e)));
+    res[0] = ok ? 1u : 0u;
+  }
+}
 int main() {
+  {
+    uint32_t* r; CK(hipMalloc(&r, 4));
+    int bad = 0;
+    for (int threads : {64, 128, 192, 256}) for (int pat = 0; pat < 5; pat++) {
+      CK(hipMemset(r, 0, 4));
+      hipLaunchKernelGGL(k_quad, dim3(1), dim3(threads), 0, 0, r, pat); CK(hipDeviceSynchronize());
+      uint32_t h = 0; CK(hipMemcpy(&h, r, 4, hipMemcpyDeviceToHost));
+      if (!h) { printf("block_sum_quad: %d lanes, pattern %d: MISMATCH\n", threads, pat); bad++; }
+    }
+    printf("block_sum_quad: %d of 20 cases wrong\n", bad);
+    if (bad) { printf("G1TEST FAIL\n"); return 1; }
+  }
   uint32_t *d, *s; CK(hipMalloc(&d, 4 * (N + 1) * 4)); CK(hipMalloc(&s, 256)); CK(hipMemset(d, 0, 4 * (N + 1) * 4));
   hipLaunchKernelGGL(k_g1, dim3(1), dim3(64), 0, 0, d, s); CK(hipDeviceSynchronize());
   static uint32_t h[4 * (N + 1)]; CK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
