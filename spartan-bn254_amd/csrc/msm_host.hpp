@@ -356,6 +356,8 @@ struct RowInfo {
   const uint8_t* flags = nullptr;   // null: no information
   bool skip_zero = false;           // no blinds: an all-zero row is the identity and needs no work at all
   size_t col_value = ~(size_t)0, col_blind = ~(size_t)0;   // the only columns a flagged row can be non-zero in
+  bool internal_rows = false;       // rows written by this library (bullet rounds): canonical and never constant, so the pass that
+                                    // classifies rows and checks the caller's scalars is skipped
 };
 static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const RowInfo& ri = RowInfo()) {
   if (L == 0) return SBN_OK;
@@ -365,7 +367,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     const size_t U = b->U; int rc;
     if ((rc = ensure(c, c->merged, L * (U + 1) * 32 + L))) return rc;
     uint32_t* m = (uint32_t*)c->merged.p; uint8_t* rowflags = (uint8_t*)c->merged.p + L * (U + 1) * 32;
-    if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, c->d_bad);
+    if (R && !ri.internal_rows) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, c->d_bad);
     else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
     LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
     if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
