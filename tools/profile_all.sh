@@ -21,7 +21,9 @@ has() { [ -z "$TAGS" ] || [[ " $TAGS " == *" $1 "* ]]; }
 B="python3 bench.py --no-cpu-baseline --blocks none"
 has msm20 && prof msm20 msm 2^20 0 -- $B --steps 40 --warmup 4
 has msm20_serial && prof msm20_serial msm 2^20 1 -- $B --steps 20 --warmup 2 --inflight 1
+has msm22 && prof msm22 msm 2^22 1 -- $B --log-n 22 --steps 6 --warmup 1 --inflight 1
 has msm24 && prof msm24 msm 2^24 1 -- $B --log-n 24 --steps 4 --warmup 1 --inflight 1
+has msm26 && prof msm26 msm 2^26 1 -- $B --log-n 26 --steps 2 --warmup 1 --inflight 1
 has hyrax_lookup && prof hyrax_lookup hyrax-lookup 4096x8192 1 -- $B --workload hyrax --steps 8 --warmup 2
 has hyrax_bucket && prof hyrax_bucket hyrax-bucket 4096x8192 1 -- $B --workload hyrax --precompute-gb 0 --steps 8 --warmup 2
 has sumcheck && prof sumcheck sumcheck 18x2^21 1 -- python3 tools/bench_sumcheck.py 21 2
