@@ -431,10 +431,18 @@ def main():
                 comb_c = 0; tpre = 0.0
                 if gb > 0:
                     tpre = time.perf_counter()
+                    err = None
                     try:
                         comb_c = ctx.bases_precompute(hb, int(gb * (1 << 30)))
                     except sbn.SbnError as e:
-                        res[name] = {"skipped": str(e)}; continue
+                        err = str(e)
+                    if world > 1:                          # the variant's steps hold a collective: every rank runs it or none does
+                        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=coll_dev)
+                        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                        if int(flag.item()) and err is None:
+                            err = "another rank could not build its lookup table"
+                    if err is not None:
+                        res[name] = {"skipped": err}; continue
                     tpre = time.perf_counter() - tpre
                 out = hy_step()
                 bad = hyrax_check(Z, out, L, Rc, (0, 7, L // 2 + 1, 3 * L // 4 - 1, 3 * L // 4, L - 1), gxy) if rank == 0 else None

@@ -27,4 +27,4 @@ has msm26 && prof msm26 msm 2^26 1 -- $B --log-n 26 --steps 2 --warmup 1 --infli
 has hyrax_lookup && prof hyrax_lookup hyrax-lookup 4096x8192 1 -- $B --workload hyrax --steps 8 --warmup 2
 has hyrax_bucket && prof hyrax_bucket hyrax-bucket 4096x8192 1 -- $B --workload hyrax --precompute-gb 0 --steps 8 --warmup 2
 has sumcheck && prof sumcheck sumcheck 18x2^21 1 -- python3 tools/bench_sumcheck.py 21 2
-has bullet && prof bullet bullet 8192 0 -- python3 tools/bench_bullet.py
+has bullet && prof bullet bullet 8192 1 -- python3 tools/bench_bullet.py
