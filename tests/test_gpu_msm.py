@@ -475,10 +475,10 @@ def _dot_arith(pr, scalars, first, n):
     return ((S0 * sum_k + DSTEP * (sum_ik + first * sum_k)) % pr.R).to_bytes(32, "little")
 
 
-@pytest.mark.parametrize("logn", [22, 23, 24])
+@pytest.mark.parametrize("logn", [22, 23, 24, 26])
 def test_large_msm_dlog_identity(ctx, ol, pr, logn):
-    """upper part of the BASELINE size range (2^23 = one GPU's share of config 4, 2^26 over 8 GPUs): window bits at the
-    16-bit cap, many chunks per window, long bucket chains; checked exactly through the discrete-log identity"""
+    """upper part of the BASELINE size range (2^23 = one GPU's share of config 4, 2^26 = all of it on one GPU): the two-level sort
+    with windows of 17 and 20 bits, long bucket chains, the short top window; checked exactly through the discrete-log identity"""
     import torch
     n = 1 << logn
     first = 12345
