@@ -394,6 +394,24 @@ def test_msm_large_skew(ctx, ol, pr):
         b.free()
 
 
+def test_msm_large_skew_two_level_sort(ctx, ol, pr):
+    """2^21 terms through the two-level sort with degenerate digit distributions: every scalar equal (one partition and one bucket
+    per window hold everything: 128 level-2 sub-chunks on one LDS counter, then 2^21-entry buckets cut into segments), and half
+    of the scalars zero / the other half r - 1 (every digit of r - 1, zero digits never enter the sort)"""
+    import torch
+    n = 1 << 21
+    b = ctx.bases_synthetic(n, 7, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+    try:
+        one = rand_scalars(1, 31)
+        for blob in (one * n, (bytes(32) + pr.scalar_to_bytes(pr.R - 1)) * (n // 2)):
+            k = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+            out, inf = ctx.msm_bases_dev(b, k.data_ptr(), n)
+            assert ctx.prof_last_job()["c"] > 16                                             # the two-level path (c = 17 at this size)
+            assert out == ol.g1_mul(pr.point_to_xy(pr.G), _dot_arith(pr, blob, 7, n)) and not inf
+    finally:
+        b.free()
+
+
 def _dev_scalars(torch, n, seed, ctx=None):
     """n scalars uniform in Fr, FULL width (bits 252 / 253 set on ~3/4 of them), generated on the device by sbn_scalars_synthetic
     (SplitMix64 reduced mod r) as an (n, 8) int32 tensor"""
