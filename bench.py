@@ -617,19 +617,25 @@ def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
         res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
         res[mode]["GBps_end_to_end"] = round(alg / (ms * 1e-3) / 1e9, 1)
     kf = res["fused"]["kernels_ms_total"]
-    fused_ms = kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)     # the pre-bind of the shared C table belongs to the round
-    if fused_ms:
-        ach = alg_fused_rounds / (fused_ms * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_bind_eval_cubic (+ k_bind_oop of the shared table)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                           "traffic": None, "kernel_ms_all_rounds": round(fused_ms, 3), "algorithmic_bytes_all_rounds": int(alg_fused_rounds),
-                           "note": "kernel-only: all fused rounds of one sumcheck (table bytes halve per round); 43 distinct tables read once, bound halves written once"}
-        # stored PMC bytes: average per launch of the streaming kernel (rounds on tables of 2^16 entries and more) x those launches;
-        # the later rounds move < 2 % of the bytes
-        npf = max(0, logn - 15)
+    # dominant kernel: the streaming fused round (tables of 2^16 entries and more) together with the out-of-place bind of the shared C
+    # table that belongs to it; the later rounds (single-launch kernel, launch-latency bound) are reported next to it
+    npf = max(0, logn - 15)
+    stream_ms = kf.get("k_sc_bind_eval_cubic_stream", 0.0) + kf.get("k_bind_oop", 0.0)
+    small_ms = kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)
+    if stream_ms and npf:
+        alg_stream = table_bytes * 1.5 * sum(0.5 ** j for j in range(npf))          # round j reads its live tables once and writes half
+        ach = alg_stream / (stream_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_bind_eval_pf<CUBIC> (+ k_bind_oop of the shared table)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": npf, "kernel_avg_ms": round(stream_ms / npf, 4),
+                           "algorithmic_bytes_per_launch": int(alg_stream / npf), "kernel_ms_streaming_rounds": round(stream_ms, 3),
+                           "note": "kernel-only, per launch averaged over the %d streaming rounds of one sumcheck (table bytes halve per round); 43 distinct tables read once, bound halves written once" % npf,
+                           "all_fused_rounds": {"kernel_ms": round(stream_ms + small_ms, 3), "algorithmic_bytes": int(alg_fused_rounds),
+                                                "GBps": round(alg_fused_rounds / ((stream_ms + small_ms) * 1e-3) / 1e9, 1),
+                                                "note": "incl. the %d launch-latency-bound rounds on tables below 2^16 entries" % (logn - 1 - npf)}}
         st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_bind_eval_pf")
-        if st and npf:
-            res["roofline"]["traffic"] = int(st[0] * npf)
-            res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per streaming launch x %d streaming rounds; not measured by this run)" % npf
+        if st:
+            res["roofline"]["traffic"] = int(st[0])
+            res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per streaming launch; not measured by this run)"
     ke = res["separate"]["kernels_ms_total"]
     if ke.get("k_sc_eval_cubic") and ke.get("k_bind_top"):
         res["separate"]["eval_GBps"] = round(2 * table_bytes / (ke["k_sc_eval_cubic"] * 1e-3) / 1e9, 1)

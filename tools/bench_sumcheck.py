@@ -80,7 +80,12 @@ def main():
         res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
         res[mode]["GBps_vs_8000"] = round(alg / (ms * 1e-3) / 1e9, 1)
     kf = res["fused"]["kernels_ms_total"]
-    fused_ms = kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)
+    stream_ms = kf.get("k_sc_bind_eval_cubic_stream", 0.0) + kf.get("k_bind_oop", 0.0)
+    npf = max(0, logn - 15)
+    if stream_ms and npf:
+        res["fused"]["streaming_rounds_ms"] = round(stream_ms, 3)
+        res["fused"]["streaming_rounds_GBps"] = round(table_bytes * 1.5 * sum(0.5 ** j for j in range(npf)) / (stream_ms * 1e-3) / 1e9, 1)
+    fused_ms = stream_ms + kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)
     res["fused"]["kernel_only_rounds_ms"] = round(fused_ms, 3)
     res["fused"]["kernel_only_rounds_GBps"] = round(2 * table_bytes * 1.5 / (fused_ms * 1e-3) / 1e9, 1) if fused_ms else None
     res["env"] = {k: v for k, v in os.environ.items() if k.startswith("SBN_")}
