@@ -125,6 +125,8 @@ __device__ __forceinline__ ScPts sc_points_u(const Fr& lo, const Fr& hi) {
   return o;
 }
 
+__device__ __forceinline__ Fr sc_point2_u(const Fr& lo, const Fr& hi) { return fe_normu(fe_add_lazy(hi, fe_subb<FrP, 3, 1>(hi, lo))); }   // 2 hi - lo + 3 r
+
 // partial[inst][block][3] (Montgomery form)
 struct ScArgsPack { ScArgs a[SC_PACK_MAX]; };
 // args == nullptr: the instances' pointers are in `pack`; tickets == nullptr: the caller runs k_sc_finish instead of the in-kernel fold
@@ -143,8 +145,8 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
     if (KIND == KIND_QUAD) {
       const Fr zl = fe_gload<FrP>(a.t[0] + 8 * i), zh = fe_gload<FrP>(a.t[0] + 8 * (i + half));
       const Fr al = fe_gload<FrP>(a.t[1] + 8 * i), ah = fe_gload<FrP>(a.t[1] + 8 * (i + half));
-      fr_acc(e0, fe_mul(zl, al), c0);
-      fr_acc(e2, fe_mul(fe_norm(fe_sub_lazy(fe_dbl_lazy(zh), zl)), fe_norm(fe_sub_lazy(fe_dbl_lazy(ah), al))), c2);
+      fr_acc(e0, fe_mulu(zl, al), c0);
+      fr_acc(e2, fe_mulu(sc_point2_u(zl, zh), sc_point2_u(al, ah)), c2);
     } else if (KIND == KIND_CUBIC) {
       const Fr al = fe_gload<FrP>(a.t[0] + 8 * i), ah = fe_gload<FrP>(a.t[0] + 8 * (i + half));
       const Fr bl = fe_gload<FrP>(a.t[1] + 8 * i), bh = fe_gload<FrP>(a.t[1] + 8 * (i + half));
@@ -158,10 +160,12 @@ __global__ void __launch_bounds__(256) k_sc_eval(const ScArgs* __restrict__ args
       const Fr al = fe_gload<FrP>(a.t[1] + 8 * i), ah = fe_gload<FrP>(a.t[1] + 8 * (i + half));
       const Fr bl = fe_gload<FrP>(a.t[2] + 8 * i), bh = fe_gload<FrP>(a.t[2] + 8 * (i + half));
       const Fr cl = fe_gload<FrP>(a.t[3] + 8 * i), ch = fe_gload<FrP>(a.t[3] + 8 * (i + half));
-      const ScPts pt = sc_points(tl, th), pa = sc_points(al, ah), pb = sc_points(bl, bh), pc = sc_points(cl, ch);
-      fr_acc(e0, fe_mul(tl, fe_sub(fe_mul(al, bl), cl)), c0);
-      fr_acc(e2, fe_mul(pt.v2, fe_sub(fe_mul(pa.v2, pb.v2), pc.v2)), c2);
-      fr_acc(e3, fe_mul(pt.v3, fe_sub(fe_mul(pa.v3, pb.v3), pc.v3)), c3);
+      // T (A B - C) on the unsigned fast path: the subtrahends are table points below 2.5 r, 8 r, 13.5 r (sc_points_u), so the
+      // differences carry 3 r, 9 r, 14 r and stay non-negative; the outer products (< 15.1 r * 13.5 r) return values below 2.3 r
+      const ScPts pt = sc_points_u(tl, th), pa = sc_points_u(al, ah), pb = sc_points_u(bl, bh), pc = sc_points_u(cl, ch);
+      fr_acc(e0, fe_mulu(tl, fe_subb<FrP, 3, 1>(fe_mulu(al, bl), cl)), c0);
+      fr_acc(e2, fe_mulu(pt.v2, fe_subb<FrP, 9, 1>(fe_mulu(pa.v2, pb.v2), pc.v2)), c2);
+      fr_acc(e3, fe_mulu(pt.v3, fe_subb<FrP, 14, 1>(fe_mulu(pa.v3, pb.v3), pc.v3)), c3);
     }
   }
   if (sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, tickets ? out : nullptr, seq)) return;
@@ -212,24 +216,21 @@ __device__ __forceinline__ ScPair sc_bound_pair(const uint32_t* __restrict__ z, 
 }
 // the running products of one index at the points 0, 2, 3 and how a table enters them
 struct ScProd { Fr p0, p2, p3; };
+// (all three comb functions run on fp.cuh's unsigned fast path: table values lie in [0, 2.5 r), their points below 8 r and 13.5 r)
 template <int KIND> __device__ __forceinline__ void sc_first(ScProd& P, const ScPair& t) {
   P.p0 = t.lo;
-  if (KIND == KIND_QUAD) { P.p2 = fe_norm(fe_sub_lazy(fe_dbl_lazy(t.hi), t.lo)); return; }
-  const ScPts v = KIND == KIND_CUBIC ? sc_points_u(t.lo, t.hi) : sc_points(t.lo, t.hi); P.p2 = v.v2; P.p3 = v.v3;
+  if (KIND == KIND_QUAD) { P.p2 = sc_point2_u(t.lo, t.hi); return; }
+  const ScPts v = sc_points_u(t.lo, t.hi); P.p2 = v.v2; P.p3 = v.v3;
 }
 template <int KIND> __device__ __forceinline__ void sc_times(ScProd& P, const ScPair& t) {
-  if (KIND == KIND_CUBIC) {                      // A*B*C: everything non-negative (see sc_points_u)
-    const ScPts v = sc_points_u(t.lo, t.hi);
-    P.p0 = fe_mulu(P.p0, t.lo); P.p2 = fe_mulu(P.p2, v.v2); P.p3 = fe_mulu(P.p3, v.v3);
-    return;
-  }
-  P.p0 = fe_mul(P.p0, t.lo);
-  if (KIND == KIND_QUAD) { P.p2 = fe_mul(P.p2, fe_norm(fe_sub_lazy(fe_dbl_lazy(t.hi), t.lo))); return; }
-  const ScPts v = sc_points(t.lo, t.hi); P.p2 = fe_mul(P.p2, v.v2); P.p3 = fe_mul(P.p3, v.v3);
+  P.p0 = fe_mulu(P.p0, t.lo);
+  if (KIND == KIND_QUAD) { P.p2 = fe_mulu(P.p2, sc_point2_u(t.lo, t.hi)); return; }
+  const ScPts v = sc_points_u(t.lo, t.hi);
+  P.p2 = fe_mulu(P.p2, v.v2); P.p3 = fe_mulu(P.p3, v.v3);
 }
-__device__ __forceinline__ void sc_minus(ScProd& P, const ScPair& t) {       // r1cs: Az*Bz - Cz
-  const ScPts v = sc_points(t.lo, t.hi);
-  P.p0 = fe_sub(P.p0, t.lo); P.p2 = fe_sub(P.p2, v.v2); P.p3 = fe_sub(P.p3, v.v3);
+__device__ __forceinline__ void sc_minus(ScProd& P, const ScPair& t) {       // r1cs: Az*Bz - Cz (+ 3 r, 9 r, 14 r: left un-carried, the next step multiplies by normalised points of tau)
+  const ScPts v = sc_points_u(t.lo, t.hi);
+  P.p0 = fe_subb<FrP, 3, 1>(P.p0, t.lo); P.p2 = fe_subb<FrP, 9, 1>(P.p2, v.v2); P.p3 = fe_subb<FrP, 14, 1>(P.p3, v.v3);
 }
 
 // WPS = waves per SIMD the register allocation is held to
