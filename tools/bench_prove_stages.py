@@ -71,10 +71,12 @@ def run(sbn, ctx):
         out = (C.c_uint8 * (96 * k))()
         if L_.sbn_sc_eval_cubic_batched(ctx.h, a, b, c_, C.c_size_t(k), out):
             raise RuntimeError("sbn_sc_eval_cubic_batched")
+        rbuf = (C.c_uint8 * 32)(); kk = C.c_size_t(k)
         while n >= 2:
-            r = challenge(bytes(out)); rounds += 1
+            r = challenge(out); rounds += 1                     # (hashlib reads the ctypes buffer in place)
             if n >= 4:
-                if L_.sbn_sc_bind_eval_cubic_batched(ctx.h, a, b, c_, C.c_size_t(k), (C.c_uint8 * 32).from_buffer_copy(r), out):
+                C.memmove(rbuf, r, 32)
+                if L_.sbn_sc_bind_eval_cubic_batched(ctx.h, a, b, c_, kk, rbuf, out):
                     raise RuntimeError("sbn_sc_bind_eval_cubic_batched")
             else:
                 ctx.bind_top_many(tabs, r)
@@ -94,7 +96,7 @@ def run(sbn, ctx):
             st, _ = ctx.bullet_begin(G, Q_xy, LZ, Rv, scal(1))
             for _ in range(log_r):
                 L, _, Rp, _, cL, cR = ctx.bullet_cross(st, scal(1), scal(1))
-                u = challenge(L + Rp); ui = pow(int.from_bytes(u, "little"), R_MOD - 2, R_MOD).to_bytes(32, "little")
+                u = challenge(L + Rp); ui = pow(int.from_bytes(u, "little"), -1, R_MOD).to_bytes(32, "little")
                 ctx.bullet_fold(st, u, ui)
             ctx.bullet_finish(st)
             st.free()
