@@ -271,6 +271,81 @@ __global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
+// The fused round on the LAST tables of a sumcheck (q = old_len / 4 <= 64 indices): four lanes per index.  A round on such a table
+// is a chain of dependent products on one wave (12 for the cubic comb function: 0.54 us each on a lone wave) followed by three wave
+// sums; here the 2 NT binds of an index are dealt over its four lanes (lane `role` binds slot role, then slot 4 + role), the
+// bound values are exchanged inside the quad by DPP, and lanes 0, 1, 2 evaluate the comb function at the points 0, 2, 3 — a chain
+// of 2 binds + 2 products (3 + 2 for R1CS, 1 + 1 quadratic) — and ONE 4-level butterfly over the quads sums all three points at
+// once.  One block per instance, results straight to the host mailbox (as sc_block_sums_store's direct path).
+// Slot s = 2 * t + h: table t in the kind's order (cubic 0,1,2 - r1cs 1,2,3,0 - quad 0,1), half h (0: lo = Z'[i], 1: hi = Z'[i + q]).
+template <int KIND>
+__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q, ScScalar rmont, uint32_t* __restrict__ mbox, uint32_t seq) {
+  constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
+  ScFusedArgs a;
+  if (args) a = args[blockIdx.y];
+  else {
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)blockIdx.y) a = pack.a[i];
+  }
+  const Fr r = fr_from_words(rmont);
+  const int lane = threadIdx.x, role = lane & 3;
+  const size_t i = (size_t)(lane >> 2);
+  const bool live = i < q;                                   // whole quads are live or not
+  Fr v[2];                                                   // the lane's bound values: slot role, slot 4 + role
+#pragma unroll
+  for (int rnd = 0; rnd < 2; rnd++) {
+    v[rnd] = fe_zero<FrP>();
+    const int slot = 4 * rnd + role;
+    if (slot < 2 * NT && live) {
+      const int tk = slot >> 1, h = slot & 1;
+      int t = 0;                                             // table index of position tk in the kind's order
+      if (KIND == KIND_R1CS) t = tk == 3 ? 0 : tk + 1; else t = tk;
+      const uint32_t* src = nullptr; uint32_t* dst = nullptr; uint32_t pre = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (j == t) { src = a.src[j]; dst = a.dst[j]; pre = a.pre[j]; }
+      const size_t e = i + (size_t)h * q;
+      if (pre) v[rnd] = fe_gload<FrP>(src + 8 * e);
+      else {
+        v[rnd] = sc_bind1(fe_gload<FrP>(src + 8 * e), fe_gload<FrP>(src + 8 * (e + 2 * q)), r);
+        if (dst) fe_gstore_packed<FrP>(dst + 8 * e, v[rnd]);
+      }
+    }
+  }
+  // every lane of the quad gets the (lo, hi) pairs of the tables in the kind's order
+  const Fr l0 = fe_quad_bcast<0>(v[0]), h0 = fe_quad_bcast<1>(v[0]), l1 = fe_quad_bcast<2>(v[0]), h1 = fe_quad_bcast<3>(v[0]);
+  const Fr l2 = fe_quad_bcast<0>(v[1]), h2 = fe_quad_bcast<1>(v[1]), l3 = fe_quad_bcast<2>(v[1]), h3 = fe_quad_bcast<3>(v[1]);
+  // lane `role` takes the point role -> 0, 2, 3 of every table (role 3 idles)
+  auto at = [&](const Fr& lo, const Fr& hi) {
+    const ScPts p = sc_points_u(lo, hi);
+    return fe_sel4(role, lo, p.v2, p.v3, lo);
+  };
+  Fr e;
+  if (KIND == KIND_QUAD) e = fe_mulu(at(l0, h0), at(l1, h1));
+  else if (KIND == KIND_CUBIC) e = fe_mulu(fe_mulu(at(l0, h0), at(l1, h1)), at(l2, h2));
+  else {
+    // tau (A B - C): the subtrahend's cover depends on the point (3 r, 9 r, 14 r: see k_sc_eval); one cover for all lanes: 14 r
+    const Fr ab = fe_mulu(at(l0, h0), at(l1, h1));
+    e = fe_mulu(at(l3, h3), fe_subb<FrP, 14, 1>(ab, at(l2, h2)));
+  }
+  const bool counts = live && role < (KIND == KIND_QUAD ? 2 : 3);
+  if (!counts) e = fe_zero<FrP>();
+  e = fe_reduce(e);
+  // sum over the quads of the wave (same role), then over the block's waves
+#pragma unroll
+  for (int d = 4; d < 64; d <<= 1) e = fe_add(e, fe_shfl_xor(e, d));
+  __shared__ uint32_t sm[4][4][NL];
+  const int wv = lane >> 6, nw = (int)(blockDim.x >> 6);
+  if ((lane & 63) < 4) { for (int k = 0; k < NL; k++) sm[wv][role][k] = e.v[k]; }
+  __syncthreads();
+  if (lane < (KIND == KIND_QUAD ? 2 : 3)) {
+    Fr s = fe_zero<FrP>();
+    for (int w = 0; w < nw; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][lane][k]; s = fe_add(s, x); }
+    fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + lane), fe_from_mont(s));
+  }
+  __syncthreads();                           // the stores happen-before the flag's release
+  if (lane == 0) __hip_atomic_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The streaming form of the fused round (tables of 2^16 entries and more): the NEXT table's elements are loaded into a second
 // register set before the current table's arithmetic starts (software pipeline over the flattened (index, table) sequence), so
 // every wave has 8 KB in flight all the time.  rocprofv3 on the plain form: SQ_WAIT_ANY (memory) drops from 21 % to 5 % of the

@@ -76,9 +76,11 @@ def test_full_prove_cubic_loop(ctx, ol, pr):
         t.free()
 
 
-@pytest.mark.parametrize("n", [4, 8, 512, 1 << 13, 1 << 16])
+@pytest.mark.parametrize("n", [4, 8, 16, 64, 256, 512, 1 << 13, 1 << 16])
 def test_fused_bind_eval_vs_oracle(ctx, ol, n):
-    """fused round == bind_top on every table, then the next round's sums (one pass instead of two)"""
+    """fused round == bind_top on every table, then the next round's sums (one pass instead of two).  n <= 256: the four-lanes-per-
+    index kernel of the last rounds (1, 2, 4, 16, 64 indices: part of a wave, one wave, four waves); 512: the single-launch kernel;
+    2^13: several blocks per instance with the ticketed fold; 2^16: the streaming kernel"""
     T, A, B, C = (rand_scalars(n, s + 3 * n) for s in (1, 2, 3, 4))
     r = rand_scalars(1, 9)
     bT, bA, bB, bC = (ol.bind_top(x, r) for x in (T, A, B, C))
