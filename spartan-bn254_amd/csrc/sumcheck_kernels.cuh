@@ -51,8 +51,16 @@ __device__ __forceinline__ Fr fr_from_words(const ScScalar& s) { return fe_unpac
 __device__ __forceinline__ Fr fr_load_coherent(const uint32_t* p) {   // written by other blocks of this launch: bypass the CU's L1
   uint32_t w[8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int k = 0; k < 8; k++) w[k] = __hip_atomic_load(p + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   return fe_unpack<FrP>(w);
+}
+// partial sums that another block of the launch will read: written THROUGH the caches (system-scope atomic stores), so that the
+// hand-over needs no device-scope release fence — on gfx950 that fence writes back every dirty line of the XCD's L2, i.e. the
+// megabytes of freshly bound table values next to these 96 bytes (measured: the round on 2^15-entry tables 95 -> see DESIGN 4.2)
+__device__ __forceinline__ void fr_store_coherent(uint32_t* p, const Fr& a) {
+  uint32_t w[8]; fe_pack<FrP>(fe_fix_tab<FrP>(fe_norm(a)), w);
+#pragma unroll
+  for (int k = 0; k < 8; k++) __hip_atomic_store(p + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
 // The block's three running sums -> partial[(inst * gridDim.x + blockIdx.x) * 3 + q] (memory format, Montgomery domain).
@@ -74,7 +82,7 @@ __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
     Fr s = fe_zero<FrP>();
     for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
     if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + threadIdx.x), fe_from_mont(s));
-    else fe_store_tab<FrP>(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
+    else fr_store_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
   }
   if (direct) {
     __syncthreads();                           // the three stores happen-before the flag's release
@@ -87,12 +95,14 @@ __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
 // (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
 __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
   __shared__ uint32_t s_last;
-  __threadfence();                         // the triple is visible device-wide before the ticket is taken
+  // The triple was written through to memory (fr_store_coherent); a workgroup-scope release makes the three writers wait for
+  // their write acknowledgements (s_waitcnt vmcnt(0)) before the barrier, and only then is the ticket taken.  No L2 write-back.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[blockIdx.y], 1u) == gridDim.x - 1) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (the partial sums are read with system-scope loads: nothing cached to invalidate)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < 3) {
     Fr s = fe_zero<FrP>();
@@ -271,15 +281,17 @@ __global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);
 }
 
-// The fused round on the LAST tables of a sumcheck (q = old_len / 4 <= 64 indices): four lanes per index.  A round on such a table
+// The fused round on the LAST tables of a sumcheck (q = old_len / 4 <= 128 indices): four lanes per index, one block per instance.  A round on such a table
 // is a chain of dependent products on one wave (12 for the cubic comb function: 0.54 us each on a lone wave) followed by three wave
 // sums; here the 2 NT binds of an index are dealt over its four lanes (lane `role` binds slot role, then slot 4 + role), the
 // bound values are exchanged inside the quad by DPP, and lanes 0, 1, 2 evaluate the comb function at the points 0, 2, 3 — a chain
 // of 2 binds + 2 products (3 + 2 for R1CS, 1 + 1 quadratic) — and ONE 4-level butterfly over the quads sums all three points at
-// once.  One block per instance, results straight to the host mailbox (as sc_block_sums_store's direct path).
+// once.  The results go straight to the host mailbox (as sc_block_sums_store's direct path).  Only for the latency-bound rounds:
+// all four lanes run the whole instruction stream, 2.4x the work per index of the lane-per-index kernel (measured: slower from
+// 512 indices on, and with several blocks per instance the ticketed fold costs 7 us: 16.8 us at 128 indices against 9.6 at 64).
 // Slot s = 2 * t + h: table t in the kind's order (cubic 0,1,2 - r1cs 1,2,3,0 - quad 0,1), half h (0: lo = Z'[i], 1: hi = Z'[i + q]).
 template <int KIND>
-__global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q, ScScalar rmont, uint32_t* __restrict__ mbox, uint32_t seq) {
+__global__ void __launch_bounds__(512) k_sc_bind_eval_tiny(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q, ScScalar rmont, uint32_t* __restrict__ mbox, uint32_t seq) {
   constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
   ScFusedArgs a;
   if (args) a = args[blockIdx.y];
@@ -333,7 +345,7 @@ __global__ void __launch_bounds__(256) k_sc_bind_eval_tiny(const ScFusedArgs* __
   // sum over the quads of the wave (same role), then over the block's waves
 #pragma unroll
   for (int d = 4; d < 64; d <<= 1) e = fe_add(e, fe_shfl_xor(e, d));
-  __shared__ uint32_t sm[4][4][NL];
+  __shared__ uint32_t sm[8][4][NL];
   const int wv = lane >> 6, nw = (int)(blockDim.x >> 6);
   if ((lane & 63) < 4) { for (int k = 0; k < NL; k++) sm[wv][role][k] = e.v[k]; }
   __syncthreads();
@@ -425,7 +437,8 @@ __device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const
 // host side: the masks this kernel is built for (anything else takes the plain kernel)
 __host__ __device__ inline bool sc_pf_mask_supported(int kind, unsigned mask) { return mask == 0 || (kind == KIND_CUBIC && mask == 4u); }
 template <int KIND>
-__global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial) {
+__global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial,
+                                                            uint32_t* __restrict__ tickets /* null: the caller runs k_sc_finish */, uint32_t* __restrict__ out, uint32_t seq) {
   ScFusedArgs a;
   if (args) a = args[blockIdx.y];
   else {
@@ -437,6 +450,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* _
   if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3);   // "par" instance: the shared C arrives bound
   else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3);
   sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, nullptr, 0u);
+  if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);     // the fold writes nothing back from L2 (fr_store_coherent)
 }
 
 // out-of-place bind of the top variable of ONE table: dst[i] = Z[i] + r (Z[i + half] - Z[i]), i < half.  Runs ahead of a fused
