@@ -4,11 +4,11 @@
 // ~2.3: a carry capture costs as much as a multiply.  29-bit limbs leave 6 spare bits in a 64-bit column: 18 products per column
 // never overflow, so the 105 captures of the 32-bit-limb product disappear (at the price of 162 instead of 128 mads) and
 // additions become 9 plain v_add_u32 with no carry chain.
-#include "../../spartan-bn254_amd/csrc/fp.cuh"
+#include "legacy/fp32.cuh"      // the round-1 layer this prototype was measured against (the shipped fp.cuh IS the 29-bit layer now)
 #include <stdio.h>
 #include <vector>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} }while(0)
-using namespace sbn;
+using namespace sbn32;
 
 constexpr uint32_t MASK29 = (1u << 29) - 1;
 struct F29 { uint32_t v[9]; };
