@@ -471,6 +471,78 @@ void orc_sc_eval_quad(const uint8_t* Z, const uint8_t* ABC, size_t len, uint8_t 
   }
   fe_to_bytes(&FR, out, &e0); fe_to_bytes(&FR, out + 32, &e2);
 }
+/* SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:165-330) with comb_func = A*B*C (every call site: product_tree.rs:275-278)
+ * and the Fiat-Shamir challenges r_j supplied by the caller (the reference squeezes them from the transcript, sumcheck.rs:282-286;
+ * the transcript is outside the path).  Per round, in the reference's order: the "par" instances against the shared C
+ * (:201-235), the "seq" instances with their own C (:238-267), the coeffs-weighted combination (:269-271), then every table bound
+ * to r_j (:289-299).  Outputs: evals = rounds x (n_par + n_seq) x (e0, e2, e3); combined = rounds x (e0, e2, e3) weighted;
+ * finals = A_par[i][0].., B_par[i][0].., C_par[0], A_seq.., B_seq.., C_seq.. (:302-318).  Field addition is associative, so the
+ * threaded partial sums give the same canonical values as the reference's left-to-right loop. */
+static void tab_to_fe(fe* o, const uint8_t* b, size_t len, int threads) {
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (size_t i = 0; i < len; i++) fe_from_bytes(&FR, &o[i], b + 32 * i);
+}
+static void cubic_sums(fe out[3], const fe* A, const fe* B, const fe* C, size_t h, int threads) {
+  fe s0 = {{0}}, s2 = {{0}}, s3 = {{0}};
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+  {
+    fe e0 = {{0}}, e2 = {{0}}, e3 = {{0}};
+#pragma omp for schedule(static) nowait
+    for (size_t i = 0; i < h; i++) {
+      fe a2, a3, b2, b3, c2, c3, t;
+      fe_mul(&FR, &t, &A[i], &B[i]); fe_mul(&FR, &t, &t, &C[i]); fe_add(&FR, &e0, &e0, &t);
+      pts(&a2, &a3, &A[i], &A[i + h]); pts(&b2, &b3, &B[i], &B[i + h]); pts(&c2, &c3, &C[i], &C[i + h]);
+      fe_mul(&FR, &t, &a2, &b2); fe_mul(&FR, &t, &t, &c2); fe_add(&FR, &e2, &e2, &t);
+      fe_mul(&FR, &t, &a3, &b3); fe_mul(&FR, &t, &t, &c3); fe_add(&FR, &e3, &e3, &t);
+    }
+#pragma omp critical
+    { fe_add(&FR, &s0, &s0, &e0); fe_add(&FR, &s2, &s2, &e2); fe_add(&FR, &s3, &s3, &e3); }
+  }
+  out[0] = s0; out[1] = s2; out[2] = s3;
+}
+static void bind_fe(fe* Z, size_t h, const fe* r, int threads) {          /* hyrax.rs:195-203 */
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) schedule(static)
+  for (size_t i = 0; i < h; i++) { fe t; fe_sub(&FR, &t, &Z[i + h], &Z[i]); fe_mul(&FR, &t, &t, r); fe_add(&FR, &Z[i], &Z[i], &t); }
+}
+void orc_sc_prove_cubic_batched(const uint8_t* const* A_par, const uint8_t* const* B_par, const uint8_t* C_par, size_t n_par,
+                                const uint8_t* const* A_seq, const uint8_t* const* B_seq, const uint8_t* const* C_seq, size_t n_seq,
+                                size_t len, size_t num_rounds, const uint8_t* coeffs, const uint8_t* challenges,
+                                uint8_t* evals, uint8_t* combined, uint8_t* finals, int threads) {
+  const size_t ninst = n_par + n_seq, ntab = 2 * n_par + (n_par ? 1 : 0) + 3 * n_seq;
+  fe** T = (fe**)malloc(sizeof(fe*) * (ntab ? ntab : 1));
+  /* table order = the order of `finals` */
+  size_t k = 0;
+  for (size_t i = 0; i < n_par; i++) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], A_par[i], len, threads); }
+  for (size_t i = 0; i < n_par; i++) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], B_par[i], len, threads); }
+  if (n_par) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], C_par, len, threads); }
+  for (size_t i = 0; i < n_seq; i++) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], A_seq[i], len, threads); }
+  for (size_t i = 0; i < n_seq; i++) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], B_seq[i], len, threads); }
+  for (size_t i = 0; i < n_seq; i++) { T[k] = (fe*)malloc(sizeof(fe) * len); tab_to_fe(T[k++], C_seq[i], len, threads); }
+  fe* co = (fe*)malloc(sizeof(fe) * (ninst ? ninst : 1));
+  for (size_t i = 0; i < ninst; i++) fe_from_bytes(&FR, &co[i], coeffs + 32 * i);
+  const size_t oCp = 2 * n_par, oAs = oCp + (n_par ? 1 : 0), oBs = oAs + n_seq, oCs = oBs + n_seq;
+  size_t cur = len;
+  for (size_t j = 0; j < num_rounds && cur >= 2; j++) {
+    const size_t h = cur / 2;
+    fe comb[3] = {{{0}}, {{0}}, {{0}}};
+    for (size_t i = 0; i < ninst; i++) {
+      fe e[3];
+      if (i < n_par) cubic_sums(e, T[i], T[n_par + i], T[oCp], h, threads);
+      else { const size_t q = i - n_par; cubic_sums(e, T[oAs + q], T[oBs + q], T[oCs + q], h, threads); }
+      for (int t = 0; t < 3; t++) {
+        if (evals) fe_to_bytes(&FR, evals + 96 * (j * ninst + i) + 32 * t, &e[t]);
+        fe w; fe_mul(&FR, &w, &e[t], &co[i]); fe_add(&FR, &comb[t], &comb[t], &w);          /* sumcheck.rs:269-271 */
+      }
+    }
+    if (combined) for (int t = 0; t < 3; t++) fe_to_bytes(&FR, combined + 96 * j + 32 * t, &comb[t]);
+    fe rj; fe_from_bytes(&FR, &rj, challenges + 32 * j);
+    for (size_t t = 0; t < ntab; t++) bind_fe(T[t], h, &rj, threads);                       /* sumcheck.rs:289-299 */
+    cur = h;
+  }
+  if (finals) for (size_t t = 0; t < ntab; t++) fe_to_bytes(&FR, finals + 32 * t, &T[t][0]);
+  for (size_t t = 0; t < ntab; t++) free(T[t]);
+  free(T); free(co);
+}
 /* unipoly.rs:28-59 — same expression order as the reference */
 void orc_unipoly_from_evals(const uint8_t* evals, size_t n, uint8_t* coeffs) {
   fe e[4], two, six, two_inv, six_inv; for (size_t i = 0; i < n; i++) fe_from_bytes(&FR, &e[i], evals + 32 * i);

@@ -74,6 +74,11 @@ void orc_bind_top(uint8_t* Z, size_t len, const uint8_t r[32]);  /* in place; fi
 void orc_sc_eval_cubic(const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, uint8_t out[96]);        /* e0,e2,e3 of A*B*C      (sumcheck.rs:111-135) */
 void orc_sc_eval_r1cs(const uint8_t* T, const uint8_t* A, const uint8_t* B, const uint8_t* C, size_t len, uint8_t out[96]); /* T*(A*B-C) (sumcheck.rs:502-530, r1csproof.rs:288-292) */
 void orc_sc_eval_quad(const uint8_t* Z, const uint8_t* ABC, size_t len, uint8_t out[64]);                        /* e0,e2 of Z*ABC         (sumcheck.rs:691-699) */
+/* prove_cubic_batched (sumcheck.rs:165-330), comb = A*B*C, challenges supplied by the caller; see the .c file for the layouts */
+void orc_sc_prove_cubic_batched(const uint8_t* const* A_par, const uint8_t* const* B_par, const uint8_t* C_par, size_t n_par,
+                                const uint8_t* const* A_seq, const uint8_t* const* B_seq, const uint8_t* const* C_seq, size_t n_seq,
+                                size_t len, size_t num_rounds, const uint8_t* coeffs, const uint8_t* challenges,
+                                uint8_t* evals, uint8_t* combined, uint8_t* finals, int threads);
 /* unipoly.rs:28-59: evals at 0,1,2[,3] -> coefficients low..high; n = 3 or 4 */
 void orc_unipoly_from_evals(const uint8_t* evals, size_t n, uint8_t* coeffs);
 void orc_unipoly_eval(const uint8_t* coeffs, size_t n, const uint8_t r[32], uint8_t out[32]);

@@ -62,6 +62,20 @@ __device__ __forceinline__ void fr_store_coherent(uint32_t* p, const Fr& a) {
 #pragma unroll
   for (int k = 0; k < 8; k++) __hip_atomic_store(p + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The storing wave waits for the write acknowledgements of everything it has stored.  Every wave that stores bytes another block (or
+// the host) will read runs this BEFORE the workgroup barrier that precedes the signal (ticket add / mailbox flag): a barrier does not
+// drain vector memory, and a workgroup-scope fence compiles to nothing on gfx950 outside threadgroup-split mode, so without this wait
+// the signal can overtake the stores (MI355X_MICROARCH.md, "Valid forms": sc1 stores -> every storing wave's vmcnt(0) -> barrier ->
+// one lane signals).  Inline asm on purpose: the compiler's own waitcnt insertion does not see a cross-wave dependency, and
+// tests/test_isa_handover.py checks the shipped code object for this instruction between the stores and the signal.
+__device__ __forceinline__ void sc_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// mailbox flag: results first (drained by their own waves, then the barrier), then a system-scope release, its write-back waited for
+// explicitly (the compiler may drop the wait behind buffer_wbl2 when it believes the wave has nothing outstanding), then the flag.
+__device__ __forceinline__ void sc_flag_store(uint32_t* flag, uint32_t seq) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
 // The block's three running sums -> partial[(inst * gridDim.x + blockIdx.x) * 3 + q] (memory format, Montgomery domain).
 // mbox != nullptr with ONE block per instance (the tables of the last ~8 rounds): the block's sums are the round's values, so
@@ -84,9 +98,10 @@ __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
     if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + threadIdx.x), fe_from_mont(s));
     else fr_store_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
   }
+  sc_drain_stores();                           // (wave 0 stored; the others have nothing outstanding) — before ANY barrier that precedes a signal
   if (direct) {
-    __syncthreads();                           // the three stores happen-before the flag's release
-    if (threadIdx.x == 0) __hip_atomic_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();                           // the three stores have been acknowledged: the flag may follow
+    if (threadIdx.x == 0) sc_flag_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq);
   }
   return direct;
 }
@@ -95,14 +110,16 @@ __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
 // (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
 __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
   __shared__ uint32_t s_last;
-  // The triple was written through to memory (fr_store_coherent); a workgroup-scope release makes the three writers wait for
-  // their write acknowledgements (s_waitcnt vmcnt(0)) before the barrier, and only then is the ticket taken.  No L2 write-back.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // The block's triple was written through to memory (fr_store_coherent) and its wave has waited for the acknowledgements
+  // (sc_drain_stores at the end of sc_block_sums_store); behind the barrier one lane takes the ticket.  No L2 write-back anywhere.
   __syncthreads();
   if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
-  __syncthreads();
+  __syncthreads();                             // the add has returned (its value was used) before any wave of the last block loads
   if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");       // (the partial sums are read with system-scope loads: nothing cached to invalidate)
+  // the partial sums are read with system-scope loads straight to registers (they bypass this CU's L1); the agent-scope acquire on
+  // top is what the hand-over rules ask for outside the measured one-workgroup-per-CU case: it invalidates this CU's L1 only
+  if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  __syncthreads();
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < 3) {
     Fr s = fe_zero<FrP>();
@@ -110,10 +127,11 @@ __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ 
     s = wave_sum_fr(fe_reduce(s));
     if (lane == 0) fe_store_packed<FrP>(out + 8 * ((size_t)blockIdx.y * 3 + wv), fe_from_mont(s));
   }
-  __syncthreads();                           // the three waves' stores happen-before the one release below
+  sc_drain_stores();                           // waves 0..2 each wait for their own result store
+  __syncthreads();                             // ... and only then does wave 0 raise the flag
   if (threadIdx.x == 0) {
-    tickets[blockIdx.y] = 0;                          // ready for the next launch
-    __hip_atomic_store(out + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&tickets[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (written through: the next launch's adds come from any XCD)
+    sc_flag_store(out + SC_MBOX_FLAGS + blockIdx.y, seq);
   }
 }
 
@@ -354,8 +372,9 @@ __global__ void __launch_bounds__(512) k_sc_bind_eval_tiny(const ScFusedArgs* __
     for (int w = 0; w < nw; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][lane][k]; s = fe_add(s, x); }
     fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + lane), fe_from_mont(s));
   }
-  __syncthreads();                           // the stores happen-before the flag's release
-  if (lane == 0) __hip_atomic_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  sc_drain_stores();                         // the storing wave waits for its acknowledgements before the barrier
+  __syncthreads();
+  if (lane == 0) sc_flag_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq);
 }
 
 // The streaming form of the fused round (tables of 2^16 entries and more): the NEXT table's elements are loaded into a second
@@ -450,7 +469,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* _
   if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3);   // "par" instance: the shared C arrives bound
   else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3);
   sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, nullptr, 0u);
-  if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);     // the fold writes nothing back from L2 (fr_store_coherent)
+  if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);     // (only the flag's system-scope release writes back: once per instance)
 }
 
 // out-of-place bind of the top variable of ONE table: dst[i] = Z[i] + r (Z[i + half] - Z[i]), i < half.  Runs ahead of a fused

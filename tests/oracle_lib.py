@@ -146,6 +146,34 @@ def sc_eval_quad(Z, ABC):
     out = _buf(64); lib().orc_sc_eval_quad(Z, ABC, C.c_size_t(len(Z) // 32), out); return _b(out)
 
 
+def sc_prove_cubic_batched(A_par, B_par, C_par, A_seq, B_seq, C_seq, coeffs, challenges, threads=8):
+    """prove_cubic_batched (sumcheck.rs:165-330) with caller-supplied challenges.  Tables: bytes-like (numpy uint8 arrays are taken
+    without a copy).  -> (evals[round][inst] = 96 B, combined[round] = 96 B, finals = list of 32 B in the order A_par.., B_par..,
+    C_par, A_seq.., B_seq.., C_seq..)"""
+    import numpy as np
+    keep = []
+
+    def ptr(x):
+        a = np.frombuffer(x, dtype=np.uint8) if not isinstance(x, np.ndarray) else x
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    def arr(lst):
+        return (C.c_void_p * max(1, len(lst)))(*[ptr(x) for x in lst])
+    n_par, n_seq = len(A_par), len(A_seq)
+    first = A_par[0] if n_par else A_seq[0]
+    ln = len(first) // 32 if not hasattr(first, "nbytes") else first.nbytes // 32
+    rounds = len(challenges) // 32
+    ninst = n_par + n_seq
+    ntab = 2 * n_par + (1 if n_par else 0) + 3 * n_seq
+    ev, cb, fin = _buf(96 * rounds * ninst), _buf(96 * rounds), _buf(32 * ntab)
+    lib().orc_sc_prove_cubic_batched(arr(A_par), arr(B_par), ptr(C_par) if n_par else None, C.c_size_t(n_par), arr(A_seq), arr(B_seq), arr(C_seq), C.c_size_t(n_seq),
+                                     C.c_size_t(ln), C.c_size_t(rounds), bytes(coeffs), bytes(challenges), ev, cb, fin, threads)
+    ev, cb, fin = _b(ev), _b(cb), _b(fin)
+    evals = [[ev[96 * (j * ninst + i):96 * (j * ninst + i + 1)] for i in range(ninst)] for j in range(rounds)]
+    return evals, [cb[96 * j:96 * j + 96] for j in range(rounds)], [fin[32 * t:32 * t + 32] for t in range(ntab)]
+
+
 def unipoly_from_evals(ev):
     n = len(ev) // 32; out = _buf(32 * n); lib().orc_unipoly_from_evals(ev, C.c_size_t(n), out); return _b(out)
 

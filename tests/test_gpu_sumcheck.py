@@ -160,11 +160,11 @@ def test_full_size_round_properties(ctx, ol, pr):
     the round sums are additive over index ranges (a checksum of checksums), and the bind is checked on slices."""
     import torch
     n = 1 << 21
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
-    raw = [torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int32, device="cuda", generator=g) for _ in range(4)]
-    for x in raw:
-        x[:, 7] &= 0x0fffffff                       # < 2^252: canonical
+    raw = [torch.empty((n, 8), dtype=torch.int32, device="cuda") for _ in range(4)]
+    for k, x in enumerate(raw):
+        ctx.scalars_synthetic(0x5BA27A2B4E254 + 500 + k, 0, n, x.data_ptr())     # uniform in Fr, full width (bits 252 / 253 set on ~3/4)
     torch.cuda.synchronize()
+    assert int((raw[0][:, 7] >> 28).max()) >= 2                                   # values above 2^253 are present
     h, q = n // 2, n // 4
 
     def tables(parts):
@@ -507,3 +507,96 @@ def test_fused_round_unspilled_build(sbn, ol):
             t.free()
     finally:
         cx.close()
+
+
+def _uniform_tables(ctx, count, n, seed):
+    """`count` tables of n uniform full-width Fr values (sbn_scalars_synthetic), as (device handles, host numpy uint8 arrays)"""
+    import torch
+    dev, host = [], []
+    for k in range(count):
+        x = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+        ctx.scalars_synthetic(0x5BA27A2B4E254 + seed + k, 0, n, x.data_ptr())
+        torch.cuda.synchronize()
+        host.append(x.cpu().numpy().view("uint8").reshape(-1))
+        dev.append(ctx.table_from_dev(x.data_ptr(), n))
+        del x
+    return dev, host
+
+
+def _run_batched_sumcheck(ctx, ol, n, n_par, n_seq, seed, threads=16):
+    """prove_cubic_batched (sumcheck.rs:165-330) on the fused path with caller-chosen challenges: every round's per-instance triples
+    and the final claims against the oracle's loop"""
+    dev, host = _uniform_tables(ctx, 2 * n_par + 1 + 3 * n_seq, n, seed)
+    Ap, Bp, Cp = dev[:n_par], dev[n_par:2 * n_par], dev[2 * n_par]
+    o = 2 * n_par + 1
+    As, Bs, Cs = dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:]
+    rounds = n.bit_length() - 1
+    ch = rand_scalars(rounds, seed + 1)
+    co = rand_scalars(n_par + n_seq, seed + 2)
+    As_all, Bs_all, Cs_all = Ap + As, Bp + Bs, [Cp] * n_par + Cs
+    got = [ctx.sc_eval_cubic_batched(As_all, Bs_all, Cs_all)]
+    for j in range(rounds):
+        r = ch[32 * j:32 * j + 32]
+        if len(dev[0]) >= 4:
+            got.append(ctx.sc_bind_eval_cubic_batched(As_all, Bs_all, Cs_all, r))      # bind to r_j + the sums of round j + 1
+        else:
+            ctx.bind_top_many(dev, r)                                                   # last round: nothing left to evaluate
+    finals = [ctx.table_read0(t) for t in dev]
+    want_ev, _, want_fin = ol.sc_prove_cubic_batched(host[:n_par], host[n_par:2 * n_par], host[2 * n_par], host[o:o + n_seq], host[o + n_seq:o + 2 * n_seq], host[o + 2 * n_seq:], co, ch, threads)
+    for t in dev:
+        t.free()
+    return got, finals, want_ev, want_fin
+
+
+def test_keyless_layer0_sumcheck_every_round(ctx, ol):
+    """The real workload shape of the ops product-circuit proof (12 "par" instances sharing C + 6 "seq" instances, tables of
+    2^21 uniform full-width Fr values, 2.69 GiB in round 0) on the fused path: ALL 21 rounds' 18 triples and the 43 final values against
+    the oracle's prove_cubic_batched loop — streaming kernel, ticketed fold, single-launch rounds and the four-lane tail in one run."""
+    n = 1 << 21
+    got, finals, want_ev, want_fin = _run_batched_sumcheck(ctx, ol, n, 12, 6, 9000)
+    assert len(got) == 21
+    for j, g in enumerate(got):
+        assert g == b"".join(want_ev[j]), f"round {j}"
+    assert finals == want_fin
+
+
+def test_handover_under_uneven_load(sbn, ctx, ol):
+    """The ticketed cross-block fold and the host mailbox of the round kernels (sumcheck_kernels.cuh: sc_last_block_fold) with the
+    chip UNEVENLY loaded: a second context keeps 2^22-point MSMs running on its own stream while fused rounds run on 2^17 .. 2^18-entry
+    tables, several blocks per instance; every word of every round is compared with the oracle.  On an idle chip a missing
+    s_waitcnt vmcnt(0) ahead of the signal hides (MI355X_MICROARCH.md: 'stale only under uneven load')."""
+    import threading
+    import torch
+    S0, DSTEP = 0x1234567, 0x89abcdef
+    other = sbn.Context(0)
+    stop = threading.Event()
+    done = []
+
+    def load():
+        n = 1 << 22
+        b = other.bases_synthetic(n, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+        x = torch.empty((n, 8), dtype=torch.int32, device="cuda")
+        other.scalars_synthetic(77, 0, n, x.data_ptr())
+        first = None
+        while not stop.is_set():
+            out = other.msm_bases_dev(b, x.data_ptr(), n)
+            first = first or out
+            assert out == first
+            done.append(1)
+        b.free()
+
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        import time
+        while not done and th.is_alive():
+            time.sleep(0.05)                    # the load is running before the rounds start
+        for rep, (logn, n_par, n_seq) in enumerate([(17, 5, 2), (18, 3, 1), (17, 12, 6), (15, 4, 0)]):
+            got, finals, want_ev, want_fin = _run_batched_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 9500 + 100 * rep)
+            for j, g in enumerate(got):
+                assert g == b"".join(want_ev[j]), f"case {rep} round {j}"
+            assert finals == want_fin
+    finally:
+        stop.set(); th.join()
+        other.close()
+    assert len(done) >= 2, "the competing MSM load did not run"

@@ -1,0 +1,137 @@
+"""CPU: the cross-block / device-to-host hand-over of the sumcheck round kernels, checked in the SHIPPED gfx950 code object.
+
+Every k_sc_* kernel that signals (the ticket `global_atomic_add`, the mailbox flag store behind `buffer_wbl2`) must have, in the
+instruction stream, `payload stores -> s_waitcnt vmcnt(0) -> s_barrier -> signal` with no payload store between the wait and the
+barrier: a barrier does not drain vector memory and a workgroup-scope fence compiles to nothing on gfx950, so the wait has to be
+in the binary (it was not in round 2: VERDICT r2 / ADVICE r2).  The flag additionally needs the wait between its release's
+`buffer_wbl2` and the store.  No GPU needed: llvm-objdump on the in-tree .so."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+from conftest import PKG_DIR
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    so = os.path.join(PKG_DIR, "libsbn254_hip.so")
+    if not os.path.exists(f"{LLVM}/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    tmp = tempfile.mkdtemp(prefix="isa_handover_")
+    try:
+        dst = os.path.join(tmp, "lib.so")
+        shutil.copy(so, dst)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", dst], check=True, stdout=subprocess.DEVNULL, cwd=tmp)
+        cos = [os.path.join(tmp, f) for f in os.listdir(tmp) if "gfx950" in f]
+        assert cos, "no gfx950 code object in the library"
+        txt = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--mcpu=gfx950", "--no-show-raw-insn", cos[0]], check=True, capture_output=True, text=True).stdout
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out, cur = {}, None
+    for line in txt.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+            continue
+        if cur is None:
+            continue
+        ins = line.split("//")[0].strip()
+        if ins and re.match(r"^[a-z]", ins):
+            out[cur].append(ins)
+    return {k: v for k, v in out.items() if re.search(r"k_sc_(eval|bind_eval)", k)}
+
+
+def is_vm_store(ins):
+    return ins.startswith(("global_store", "flat_store", "buffer_store"))
+
+
+def is_drain(ins):
+    # s_waitcnt vmcnt(0) possibly with other counters
+    return ins.startswith("s_waitcnt") and "vmcnt(0)" in ins
+
+
+def is_flag_store(code, k):
+    if not (code[k].startswith("global_store_dword ") and "sc0 sc1" in code[k]):
+        return False
+    return any(c.startswith("buffer_wbl2") for c in code[max(0, k - 12):k])
+
+
+def check_signal(name, code, idx, what):
+    """walk back from the signal at code[idx]: barrier first, then a drain before any vector-memory store"""
+    j = idx - 1
+    while j >= 0 and code[j] != "s_barrier":
+        assert not (is_vm_store(code[j]) and "x4" in code[j]), f"{name}: payload store between the barrier and the {what}"
+        j -= 1
+    assert j >= 0, f"{name}: no barrier ahead of the {what}"
+    k = j - 1
+    while k >= 0:
+        if is_flag_store(code, k):
+            # a mailbox-flag block of ANOTHER control-flow path laid out in between (the one-block-per-instance path stores its flag and
+            # returns): [s_barrier .. buffer_wbl2 .. flag] is skipped whole, its own waits do not count for this path
+            while k >= 0 and code[k] != "s_barrier":
+                k -= 1
+            k -= 1
+            continue
+        if is_drain(code[k]):
+            return
+        assert not is_vm_store(code[k]), f"{name}: `{code[k]}` reaches the barrier ahead of the {what} with no s_waitcnt vmcnt(0) behind it"
+        assert code[k] != "s_barrier", f"{name}: no s_waitcnt vmcnt(0) between the stores and the barrier ahead of the {what}"
+        k -= 1
+    raise AssertionError(f"{name}: nothing ahead of the {what}")
+
+
+def test_kernels_found(kernels):
+    names = " ".join(kernels)
+    for frag in ("k_sc_evalILi0", "k_sc_evalILi1", "k_sc_evalILi2", "k_sc_bind_eval_pfILi0", "k_sc_bind_eval_tinyILi0", "k_sc_bind_evalILi0ELi2"):
+        assert frag in names, f"{frag} missing from the code object"
+
+
+def test_ticket_follows_drained_stores(kernels):
+    seen = 0
+    for name, code in kernels.items():
+        for i, ins in enumerate(code):
+            if ins.startswith("global_atomic_add"):
+                seen += 1
+                check_signal(name, code, i, "ticket add")
+                # the partial sums in front of it are write-through stores
+                lo = max(0, i - 400)
+                wt = [k for k in range(lo, i) if code[k].startswith("global_store_dword ") and "sc0 sc1" in code[k] and not is_flag_store(code, k)]
+                assert len(wt) >= 8, f"{name}: the block's partial sums are not written through (sc0 sc1 dword stores) ahead of the ticket"
+    assert seen >= 12, f"only {seen} ticket adds found"           # 3 eval + 3 streaming + 9 plain fused kernels
+
+
+def test_partial_sums_read_past_l1(kernels):
+    for name, code in kernels.items():
+        adds = [i for i, c in enumerate(code) if c.startswith("global_atomic_add")]
+        for i in adds:
+            # the fold that follows reads the other blocks' sums with sc0 sc1 loads, behind an agent acquire
+            tail = code[i:i + 200]
+            assert any(c.startswith("buffer_inv sc1") for c in tail), f"{name}: no agent-scope acquire behind the ticket"
+            loads = [c for c in tail if c.startswith("global_load_dword ")]
+            assert loads and all("sc0 sc1" in c for c in loads[:8]), f"{name}: partial sums are read with cacheable loads"
+
+
+def test_mailbox_flag_follows_drained_results(kernels):
+    seen = 0
+    for name, code in kernels.items():
+        for i, ins in enumerate(code):
+            if not ins.startswith("buffer_wbl2"):
+                continue
+            # the flag: the first sc0 sc1 dword store behind the write-back, with the write-back waited for in between
+            j = i + 1
+            waited = False
+            while j < len(code) and not (code[j].startswith("global_store_dword ") and "sc0 sc1" in code[j]):
+                waited |= is_drain(code[j])
+                assert not code[j].startswith("s_endpgm"), f"{name}: buffer_wbl2 without a flag store"
+                j += 1
+            assert j < len(code) and j - i < 16, f"{name}: no flag store behind buffer_wbl2"
+            assert waited, f"{name}: the flag store may overtake the release's write-back (no s_waitcnt vmcnt(0) in between)"
+            check_signal(name, code, i, "mailbox flag")
+            seen += 1
+    assert seen >= 15, f"only {seen} mailbox flags found"

@@ -216,3 +216,54 @@ def test_oracle_bullet_vs_python_model(ol):
         o = ol.bullet_prove(H(case["G"]), H(case["Q"]), H(case["H"]), H(case["a"]), H(case["b"]), H(case["blind"]), H(case["blinds_vec"]), H(case["us"]))
         for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
             assert o[k] == H(case[k]), (case["n"], k)
+
+
+def test_prove_cubic_batched_loop_vs_round_functions(ol, pr):
+    """orc_sc_prove_cubic_batched (sumcheck.rs:165-330, threaded) against the per-round oracle functions that the golden vectors pin
+    (sc_eval_cubic, bind_top) and a big-integer check of the coeffs combination (sumcheck.rs:269-271) and of the verifier's relation
+    p(0) + p(1) == claim (sumcheck.rs:35-86) driven with the combined values."""
+    from conftest import fr_bytes, rand_scalars
+    n, n_par, n_seq = 64, 3, 2
+    Ap = [rand_scalars(n, 10 + i) for i in range(n_par)]; Bp = [rand_scalars(n, 20 + i) for i in range(n_par)]; Cp = rand_scalars(n, 30)
+    As = [rand_scalars(n, 40 + i) for i in range(n_seq)]; Bs = [rand_scalars(n, 50 + i) for i in range(n_seq)]; Cs = [rand_scalars(n, 60 + i) for i in range(n_seq)]
+    co = rand_scalars(n_par + n_seq, 70); ch = rand_scalars(6, 80)
+    for threads in (1, 3):
+        evals, comb, fin = ol.sc_prove_cubic_batched(Ap, Bp, Cp, As, Bs, Cs, co, ch, threads)
+        hA, hB, hC, sA, sB, sC = list(Ap), list(Bp), Cp, list(As), list(Bs), list(Cs)
+        ints = lambda b: [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(len(b) // 32)]
+        cs = ints(co)
+        claim = None
+        for j in range(6):
+            want = [ol.sc_eval_cubic(hA[i], hB[i], hC) for i in range(n_par)] + [ol.sc_eval_cubic(sA[i], sB[i], sC[i]) for i in range(n_seq)]
+            assert evals[j] == want, j
+            cw = [sum(c * ints(e)[t] for c, e in zip(cs, want)) % pr.R for t in range(3)]
+            assert comb[j] == fr_bytes(cw), j
+            if claim is not None:                                   # the round polynomial through (e0, claim - e0, e2, e3) evaluates consistently
+                poly = ol.unipoly_from_evals(fr_bytes([cw[0], (claim - cw[0]) % pr.R, cw[1], cw[2]]))
+                pc = ints(poly)
+                assert (pc[0] + sum(pc)) % pr.R == claim
+            r = ch[32 * j:32 * j + 32]
+            # next claim = p(r_j) where p interpolates the combined values with e1 = sum over the upper half of the cube (computed directly)
+            upper = 0
+            for i in range(n_par):
+                h = len(hA[i]) // 64
+                upper += cs[i] * sum(a * b * c for a, b, c in zip(ints(hA[i])[h:], ints(hB[i])[h:], ints(hC)[h:]))
+            for i in range(n_seq):
+                h = len(sA[i]) // 64
+                upper += cs[n_par + i] * sum(a * b * c for a, b, c in zip(ints(sA[i])[h:], ints(sB[i])[h:], ints(sC[i])[h:]))
+            poly = ol.unipoly_from_evals(fr_bytes([cw[0], upper % pr.R, cw[1], cw[2]]))
+            claim = int.from_bytes(ol.unipoly_eval(poly, r), "little")
+            hA = [ol.bind_top(x, r) for x in hA]; hB = [ol.bind_top(x, r) for x in hB]; hC = ol.bind_top(hC, r)
+            sA = [ol.bind_top(x, r) for x in sA]; sB = [ol.bind_top(x, r) for x in sB]; sC = [ol.bind_top(x, r) for x in sC]
+        assert fin == [x[:32] for x in hA] + [x[:32] for x in hB] + [hC[:32]] + [x[:32] for x in sA] + [x[:32] for x in sB] + [x[:32] for x in sC]
+        # after the last round the claim is the combination of the final products (what the verifier checks, product_tree.rs:430-460)
+        f = [int.from_bytes(x, "little") for x in fin]
+        total = sum(cs[i] * f[i] * f[n_par + i] * f[2 * n_par] for i in range(n_par))
+        o = 2 * n_par + 1
+        total += sum(cs[n_par + i] * f[o + i] * f[o + n_seq + i] * f[o + 2 * n_seq + i] for i in range(n_seq))
+        assert total % pr.R == claim
+    # no par instances / no seq instances
+    ev2, cb2, fin2 = ol.sc_prove_cubic_batched([], [], None, As, Bs, Cs, co[:64], ch[:64], 2)
+    assert ev2[0] == [ol.sc_eval_cubic(As[i], Bs[i], Cs[i]) for i in range(n_seq)] and len(fin2) == 6
+    ev3, cb3, fin3 = ol.sc_prove_cubic_batched(Ap, Bp, Cp, [], [], [], co[:96], ch[:32], 2)
+    assert ev3[0] == [ol.sc_eval_cubic(Ap[i], Bp[i], Cp) for i in range(n_par)] and len(fin3) == 7
