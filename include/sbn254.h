@@ -153,6 +153,25 @@ int sbn_sc_bind_eval_cubic_batched(sbn_ctx* ctx, sbn_table* const* A, sbn_table*
                                    const uint8_t r[32], uint8_t* out /* count x 96 */);
 int sbn_sc_bind_eval_r1cs(sbn_ctx* ctx, sbn_table* tau, sbn_table* Az, sbn_table* Bz, sbn_table* Cz, const uint8_t r[32], uint8_t out[96]);
 int sbn_sc_bind_eval_quad(sbn_ctx* ctx, sbn_table* Z, sbn_table* ABC, const uint8_t r[32], uint8_t out[64]);
+/* ---- SumcheckInstanceProof::prove_cubic_batched (sumcheck.rs:165-330; comb_func = A*B*C, its only call sites product_tree.rs:275-278)
+ *      as a device-resident state; the transcript stays with the caller:
+ *        begin -> evals of round 0;  per round: (UniPoly::from_evals, absorb, squeeze r_j) -> round(r_j) -> evals of round j+1;  finish.
+ * What crosses the boundary per round is what the transcript absorbs: the coeffs-weighted combination of the instances' sums
+ * (sumcheck.rs:269-271), i.e. (e0, e2, e3) = sum_i coeffs[i] * (e0, e2, e3)_i as three canonical scalars — not the per-instance
+ * triples.  The "par" instances share C_par (:201-235), the "seq" instances have their own C (:238-267); coeffs: n_par + n_seq
+ * canonical scalars, "par" first.  n_par + n_seq <= 24.  The caller's tables are only read: the state binds into buffers of its own.
+ * Same field elements as the per-instance calls + a host-side combination, bit for bit. */
+typedef struct sbn_sumcheck sbn_sumcheck;
+int sbn_sumcheck_begin(sbn_ctx* ctx, const sbn_table* const* A_par, const sbn_table* const* B_par, const sbn_table* C_par, size_t n_par,
+                       const sbn_table* const* A_seq, const sbn_table* const* B_seq, const sbn_table* const* C_seq, size_t n_seq,
+                       const uint8_t* coeffs, uint8_t out_evals[96], sbn_sumcheck** out);
+/* bind every table to r_j (sumcheck.rs:289-299); out_evals = the combined sums of the next round (zeros after the last bind) */
+int sbn_sumcheck_round(sbn_ctx* ctx, sbn_sumcheck* st, const uint8_t r[32], uint8_t out_evals[96]);
+size_t sbn_sumcheck_len(const sbn_sumcheck* st);                       /* current table length (halves per round) */
+/* after the last round (length 1): poly[0] of every table (sumcheck.rs:302-318), 32 B each, in the order
+ * A_par[0..n_par), B_par[0..n_par), C_par, A_seq[..], B_seq[..], C_seq[..] */
+int sbn_sumcheck_finish(sbn_ctx* ctx, sbn_sumcheck* st, uint8_t* finals);
+void sbn_sumcheck_free(sbn_ctx* ctx, sbn_sumcheck* st);
 /* EqPolynomial::evals (hyrax.rs:355-369) built on the device */
 int sbn_eq_evals(sbn_ctx* ctx, const uint8_t* r, size_t ell, sbn_table** out);
 

@@ -15,6 +15,7 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
+    "sbn_sumcheck_begin", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
@@ -58,8 +59,9 @@ def lib():
         L.sbn_bases_len.restype = C.c_size_t
         L.sbn_table_len.restype = C.c_size_t
         L.sbn_bullet_len.restype = C.c_size_t
+        L.sbn_sumcheck_len.restype = C.c_size_t
         L.sbn_factored_lens.restype = None
-        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free", "sbn_bullet_free"):
+        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free", "sbn_bullet_free", "sbn_sumcheck_free"):
             getattr(L, name).restype = None
         _LIB = L
     return _LIB
@@ -141,6 +143,31 @@ class Bullet:
     def free(self):
         if self.h:
             lib().sbn_bullet_free(self.ctx.h, self.h)
+            self.h = None
+
+
+class Sumcheck:
+    """prove_cubic_batched (sumcheck.rs:165-330) as a device-resident state (sbn_sumcheck_*)"""
+
+    def __init__(self, ctx, handle, n_par, n_seq):
+        self.ctx, self.h, self.ntab = ctx, handle, 2 * n_par + (1 if n_par else 0) + 3 * n_seq
+
+    def __len__(self):
+        return lib().sbn_sumcheck_len(self.h)
+
+    def round(self, r):
+        out = (C.c_uint8 * 96)()
+        self.ctx._chk(lib().sbn_sumcheck_round(self.ctx.h, self.h, _ptr(r), out), "sbn_sumcheck_round")
+        return bytes(out)
+
+    def finish(self):
+        out = (C.c_uint8 * (32 * self.ntab))()
+        self.ctx._chk(lib().sbn_sumcheck_finish(self.ctx.h, self.h, out), "sbn_sumcheck_finish")
+        return [bytes(out[32 * t:32 * t + 32]) for t in range(self.ntab)]
+
+    def free(self):
+        if self.h:
+            lib().sbn_sumcheck_free(self.ctx.h, self.h)
             self.h = None
 
 
@@ -325,6 +352,14 @@ class Context:
 
     def sc_bind_eval_quad(self, Z, ABC, r):
         out = (C.c_uint8 * 64)(); self._chk(lib().sbn_sc_bind_eval_quad(self.h, Z.h, ABC.h, _ptr(r), out), "sbn_sc_bind_eval_quad"); return bytes(out)
+
+    def sumcheck_begin(self, A_par, B_par, C_par, A_seq, B_seq, C_seq, coeffs):
+        """-> (Sumcheck state, the combined (e0, e2, e3) of round 0)"""
+        mk = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.h for t in ts])
+        st = C.c_void_p(); out = (C.c_uint8 * 96)()
+        self._chk(lib().sbn_sumcheck_begin(self.h, mk(A_par), mk(B_par), C_par.h if C_par is not None else None, C.c_size_t(len(A_par)),
+                                           mk(A_seq), mk(B_seq), mk(C_seq), C.c_size_t(len(A_seq)), _ptr(coeffs), out, C.byref(st)), "sbn_sumcheck_begin")
+        return Sumcheck(self, st, len(A_par), len(A_seq)), bytes(out)
 
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()

@@ -149,6 +149,42 @@ static inline El inv_small(uint64_t k) {           // 1/k for k in {2, 6}: (r*m 
   for (int i = 4; i >= 0; i--) { u128 cur = (rem << 64) | t[i]; uint64_t d = (uint64_t)(cur / k); rem = cur % k; if (i < 4) q.v[i] = d; }
   return q;
 }
+// Montgomery product a * b * 2^-256 mod r (CIOS, 4 x 64-bit limbs): what the stateful sumcheck's host side uses to combine the
+// "seq" instances' sums with coeffs and to recover the final claims (a few dozen products per round; the shift-and-add mul above
+// costs microseconds each).  mmul(to_m(a), b) = a * b for canonical a, b.
+static const uint64_t NINV = 0xc2e1f593efffffffull;
+static const uint64_t R2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull};   // 2^512 mod r
+static inline El mmul(const El& a, const El& b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < 4; j++) { u128 s = (u128)a.v[j] * b.v[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    u128 s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+    const uint64_t m = t[0] * NINV;
+    s = (u128)m * P[0] + t[0]; c = (uint64_t)(s >> 64);
+    for (int j = 1; j < 4; j++) { s = (u128)m * P[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+  }
+  El r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq(r.v)) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)r.v[i] - P[i] - br; r.v[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } }
+  return r;
+}
+static inline El to_m(const El& a) { El r2; memcpy(r2.v, R2, 32); return mmul(a, r2); }                 // a * 2^256
+static inline El from_m(const El& a) { return mmul(a, from_u64(1)); }
+static inline bool is_zero(const El& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+// 1 / a for a != 0, canonical in and out (Fermat; a few hundred products: once per sumcheck, never per round)
+static inline El inv(const El& a) {
+  const uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
+  const El am = to_m(a);
+  El acc = to_m(from_u64(1));
+  for (int i = 255; i >= 0; i--) { acc = mmul(acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mmul(acc, am); }
+  return from_m(acc);
+}
+// canonical x -> the device's table representation x * 2^261 mod r (fp.cuh's Montgomery domain), canonical
+static inline El to_dev_mont(const El& x) {
+  static const El K = [] { El k; memcpy(k.v, R2, 32); for (int i = 0; i < 5; i++) k = add(k, k); return k; }();    // 2^517 mod r
+  return mmul(x, K);
+}
 }  // namespace fr
 
 }  // namespace sbn_host

@@ -64,6 +64,11 @@ static bool sort2_set_lds() {
 #define X(C) if (hipFuncSetAttribute((const void*)k_s2_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
   S2_FOR_EACH_C(X)
 #undef X
+  // k_s2_count keeps W * P counters: up to 24 windows x S2_P_MAX partitions (SBN_SORT2_LO can push P to the maximum with a narrow window)
+  const int cnt_bytes = 24 * S2_P_MAX * 4;
+#define X(C) if (hipFuncSetAttribute((const void*)k_s2_count<C>, hipFuncAttributeMaxDynamicSharedMemorySize, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  S2_FOR_EACH_C(X)
+#undef X
   return ok;
 }
 static bool sort2_applies(const sbn_ctx* c, int mode, size_t n, int cbits) {
@@ -93,6 +98,7 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
   uint32_t* cntA = (uint32_t*)c->s2_cnt.p; uint32_t* part_cnt = (uint32_t*)c->s2_part.p; uint32_t* part_off = part_cnt + WP; uint32_t* sc_off = part_off + WP;
   uint32_t* tmp_idx = (uint32_t*)c->s2_idx.p; uint16_t* tmp_lo = (uint16_t*)c->s2_lo.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
   const size_t lds_a = WP * 4, lds_c = s2_scatter_lds_bytes(g.P);
+  if (lds_a > (size_t)24 * S2_P_MAX * 4) return fail(c, SBN_EINVAL, "two-level sort: %zu level-1 counters do not fit the LDS granted to k_s2_count", WP);
   {
     ProfScope _ps(c, "k_s2_count");
     switch (s.c) {
@@ -122,6 +128,7 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
     else hipLaunchKernelGGL(k_s2_place<8>, dim3(l2), dim3(1024), s2_place_lds_bytes<8>(g.lo_log), c->stream, S2_PLACE_ARGS);
 #undef S2_PLACE_ARGS
   }
+  LAUNCHCHK(c);            // a refused launch (LDS, grid) is reported here, by the sort, not by whatever runs next
   return SBN_OK;
 }
 

@@ -12,6 +12,7 @@
 #include "sort2_kernels.cuh"
 #include "comb_kernels.cuh"
 #include "sumcheck_kernels.cuh"
+#include "sumcheck_comb_kernels.cuh"
 #include "host_keccak.hpp"
 
 #include <hip/hip_runtime.h>
@@ -21,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -33,6 +35,7 @@ using namespace sbn;
 
 #include "abi_msm.inc"
 #include "abi_tables.inc"
+#include "abi_sumcheck.inc"
 #include "abi_bullet.inc"
 
 extern "C" {

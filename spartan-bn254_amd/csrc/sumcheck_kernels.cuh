@@ -38,6 +38,11 @@ __device__ __forceinline__ void fr_acc(Fr& acc, const Fr& x, uint32_t& cnt) {
   acc = fe_add(acc, x);
   if ((++cnt & 63u) == 0) acc = fe_reduce(acc);
 }
+// the same for terms up to 4 r (fe_reduce takes values below 169 r): a reduction every 32 terms
+__device__ __forceinline__ void fr_acc32(Fr& acc, const Fr& x, uint32_t& cnt) {
+  acc = fe_add(acc, x);
+  if ((++cnt & 31u) == 0) acc = fe_reduce(acc);
+}
 
 // ---- single-launch rounds -------------------------------------------------------------------------------------------
 // A sumcheck round is a host round trip (the next challenge comes from the transcript), and below ~2^16 entries the trip,
@@ -81,7 +86,8 @@ constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags
 // mbox != nullptr with ONE block per instance (the tables of the last ~8 rounds): the block's sums are the round's values, so
 // they go straight to the host mailbox as canonical integers and the flag follows — no partial sums, no ticket, no device fence.
 // Returns true when it finished the round that way.
-__device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq) {
+// slot = the "instance" index of the partial-sum / ticket / mailbox arrays (blockIdx.y for the per-instance kernels)
+__device__ __forceinline__ bool sc_block_sums_store_slot(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq, uint32_t slot) {
   __shared__ uint32_t sm[4][3][NL];
   e0 = wave_sum_fr(fe_reduce(e0)); e2 = wave_sum_fr(fe_reduce(e2));
   if (three) e3 = wave_sum_fr(fe_reduce(e3));
@@ -95,25 +101,31 @@ __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool th
   if (threadIdx.x < 3) {
     Fr s = fe_zero<FrP>();
     for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
-    if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)blockIdx.y * 3 + threadIdx.x), fe_from_mont(s));
-    else fr_store_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
+    if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)slot * 3 + threadIdx.x), fe_from_mont(s));
+    else fr_store_coherent(partial + 8 * (((size_t)slot * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
   }
   sc_drain_stores();                           // (wave 0 stored; the others have nothing outstanding) — before ANY barrier that precedes a signal
   if (direct) {
     __syncthreads();                           // the three stores have been acknowledged: the flag may follow
-    if (threadIdx.x == 0) sc_flag_store(mbox + SC_MBOX_FLAGS + blockIdx.y, seq);
+    if (threadIdx.x == 0) sc_flag_store(mbox + SC_MBOX_FLAGS + slot, seq);
   }
   return direct;
+}
+__device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq) {
+  return sc_block_sums_store_slot(e0, e2, e3, three, partial, mbox, seq, blockIdx.y);
+}
+__device__ __forceinline__ void sc_block_sums_store_at(Fr e0, Fr e2, Fr e3, uint32_t* __restrict__ partial, uint32_t slot) {
+  sc_block_sums_store_slot(e0, e2, e3, true, partial, nullptr, 0u, slot);
 }
 // Called by all 256 threads after the block's triple went to partial[...] (several blocks per instance).  nq = 2 or 3.
 // `out` = mailbox in coherent pinned host memory: 24 x 96 B of results, then one flag word per instance; the flag is stored
 // (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
-__device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
+__device__ __forceinline__ void sc_last_block_fold_at(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq, uint32_t slot) {
   __shared__ uint32_t s_last;
   // The block's triple was written through to memory (fr_store_coherent) and its wave has waited for the acknowledgements
   // (sc_drain_stores at the end of sc_block_sums_store); behind the barrier one lane takes the ticket.  No L2 write-back anywhere.
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
   __syncthreads();                             // the add has returned (its value was used) before any wave of the last block loads
   if (!s_last) return;
   // the partial sums are read with system-scope loads straight to registers (they bypass this CU's L1); the agent-scope acquire on
@@ -123,16 +135,19 @@ __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < 3) {
     Fr s = fe_zero<FrP>();
-    if (wv < nq) for (unsigned b = lane; b < gridDim.x; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)blockIdx.y * gridDim.x + b) * 3 + wv)));
+    if (wv < nq) for (unsigned b = lane; b < gridDim.x; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)slot * gridDim.x + b) * 3 + wv)));
     s = wave_sum_fr(fe_reduce(s));
-    if (lane == 0) fe_store_packed<FrP>(out + 8 * ((size_t)blockIdx.y * 3 + wv), fe_from_mont(s));
+    if (lane == 0) fe_store_packed<FrP>(out + 8 * ((size_t)slot * 3 + wv), fe_from_mont(s));
   }
   sc_drain_stores();                           // waves 0..2 each wait for their own result store
   __syncthreads();                             // ... and only then does wave 0 raise the flag
   if (threadIdx.x == 0) {
-    __hip_atomic_store(&tickets[blockIdx.y], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (written through: the next launch's adds come from any XCD)
-    sc_flag_store(out + SC_MBOX_FLAGS + blockIdx.y, seq);
+    __hip_atomic_store(&tickets[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (written through: the next launch's adds come from any XCD)
+    sc_flag_store(out + SC_MBOX_FLAGS + slot, seq);
   }
+}
+__device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
+  sc_last_block_fold_at(partial, tickets, out, nq, seq, blockIdx.y);
 }
 
 // The values of one table's line lo + t (hi - lo) at t = 2 and 3: p(2) = 2 hi - lo, p(3) = p(2) + hi - lo  (sumcheck.rs:111-135),
@@ -143,9 +158,9 @@ __device__ __forceinline__ ScPts sc_points(const Fr& lo, const Fr& hi) {
   ScPts o; o.v2 = fe_norm(fe_add_lazy(hi, d)); o.v3 = fe_norm(fe_add_lazy(o.v2, d));
   return o;
 }
-// The same on fp.cuh's unsigned fast path, for table values in [0, 2.01 r) (what this library's sumcheck tables hold): the
-// difference carries 3r, so v2 = 2 hi - lo + 3r < 7r and v3 = 3 hi - 2 lo + 6r < 12r, all limbs non-negative
-// (12r * 12r = 144 r^2 is inside the product's 169 r^2 operand limit).
+// The same on fp.cuh's unsigned fast path, for table values in [0, 2.5 r) (what this library's sumcheck tables hold: fe_fix_tab):
+// the difference carries 3r, so v2 = 2 hi - lo + 3r < 8r and v3 = 3 hi - 2 lo + 6r < 13.5r, all limbs non-negative
+// (13.5r * 13.5r = 182 r^2 / 2^261 = 1.08 r: a product of two such points comes back below 2.1 r).
 __device__ __forceinline__ ScPts sc_points_u(const Fr& lo, const Fr& hi) {
   const Fr d = fe_subb<FrP, 3, 1>(hi, lo);
   const Fr v2 = fe_add_lazy(hi, d);
@@ -219,8 +234,8 @@ struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
 
 // z0 + r (z2 - z0) as the table representative in [0, 2.5 r) that is stored and used: z0, z2 are table values (normalised,
 // below 2.5 r), their limb-wise difference is a legal product operand, the product lies in (-0.1 r, 1.1 r)
-// On the unsigned fast path: table values lie in [0, 2.01 r) (normalised), the difference carries 3r, the product of the
-// canonical challenge with it lies in [0, 1.1 r), and the sum (< 3.1 r) drops 2r when its top limb says it reached 2r — decided on
+// On the unsigned fast path: table values lie in [0, 2.5 r) (normalised), the difference carries 3r (below 5.5 r), the product of the
+// canonical challenge with it lies in [0, 1.1 r), and the sum (< 3.6 r) drops 2r when its top limb says it reached 2r — decided on
 // the un-carried top limb (the lower limbs add at most one unit to it), so one carry pass serves the sum and the correction.
 __device__ __forceinline__ Fr sc_bind1(const Fr& z0, const Fr& z2, const Fr& r) {
   Fr x = fe_add_lazy(z0, fe_mulu(r, fe_subb<FrP, 3, 1>(z2, z0)));

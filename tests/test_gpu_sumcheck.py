@@ -600,3 +600,95 @@ def test_handover_under_uneven_load(sbn, ctx, ol):
         stop.set(); th.join()
         other.close()
     assert len(done) >= 2, "the competing MSM load did not run"
+
+
+def _run_stateful_sumcheck(ctx, ol, n, n_par, n_seq, seed, coeffs=None, threads=16):
+    """sbn_sumcheck_begin / round / finish == the oracle's prove_cubic_batched: the coeffs-combined (e0, e2, e3) of every round
+    (sumcheck.rs:269-271) and the final claims (:302-318).  The caller's tables must come back untouched."""
+    dev, host = _uniform_tables(ctx, 2 * n_par + (1 if n_par else 0) + 3 * n_seq, n, seed)
+    o = 2 * n_par + (1 if n_par else 0)
+    Ap, Bp, Cp = dev[:n_par], dev[n_par:2 * n_par], (dev[2 * n_par] if n_par else None)
+    As, Bs, Cs = dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:]
+    rounds = n.bit_length() - 1
+    ch = rand_scalars(rounds, seed + 1)
+    co = coeffs if coeffs is not None else rand_scalars(n_par + n_seq, seed + 2)
+    st, ev = ctx.sumcheck_begin(Ap, Bp, Cp, As, Bs, Cs, co)
+    got = [ev]
+    for j in range(rounds):
+        assert len(st) == n >> j
+        ev = st.round(ch[32 * j:32 * j + 32])
+        if j + 1 < rounds:
+            got.append(ev)
+        else:
+            assert ev == bytes(96)
+    finals = st.finish()
+    st.free()
+    _, want_comb, want_fin = ol.sc_prove_cubic_batched(host[:n_par], host[n_par:2 * n_par], host[2 * n_par] if n_par else None, host[o:o + n_seq], host[o + n_seq:o + 2 * n_seq], host[o + 2 * n_seq:], co, ch, threads)
+    for j in range(rounds):
+        assert got[j] == want_comb[j], f"round {j} of {rounds} (n = {n}, {n_par} par + {n_seq} seq)"
+    assert finals == want_fin
+    # the state never writes the caller's tables
+    for k in (0, len(dev) - 1):
+        assert len(dev[k]) == n
+    if n <= 1 << 12:
+        assert ctx.table_download(dev[0]) == host[0].tobytes()
+    for t in dev:
+        t.free()
+
+
+@pytest.mark.parametrize("logn,n_par,n_seq", [(1, 1, 0), (1, 3, 2), (2, 2, 1), (3, 12, 6), (6, 1, 1), (9, 4, 0), (10, 12, 6), (10, 0, 3), (12, 18, 6), (14, 5, 2)])
+def test_stateful_sumcheck_small(ctx, ol, logn, n_par, n_seq):
+    """tables below 2^15 entries: the "par" A tables are scaled by coeffs when the sumcheck begins, per-instance kernels after that"""
+    _run_stateful_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 7000 + 10 * logn + n_par)
+
+
+@pytest.mark.parametrize("logn,n_par,n_seq", [(15, 2, 0), (15, 12, 6), (16, 4, 0), (16, 13, 3), (17, 16, 0), (17, 20, 4), (18, 7, 1), (19, 12, 0)])
+def test_stateful_sumcheck_combined_kernels(ctx, ol, logn, n_par, n_seq):
+    """tables of 2^15 entries and more: the combined kernels (coefficients folded into A at the first bind, one reduction per index for
+    all instances, several groups when the round is small or the instances many), then the per-instance kernels on the scaled tables"""
+    _run_stateful_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 7500 + 10 * logn + n_par)
+
+
+def test_stateful_sumcheck_modes_agree(ctx, ol, pr):
+    """a zero coefficient among the "par" instances (no inverse: nothing is scaled, the host weighs every triple), and SBN_SC_NO_COMB /
+    SBN_SC_NO_COMB_KERNEL forcing the other two modes onto a size the combined kernels would take: all equal to the oracle"""
+    import os
+    co = bytearray(rand_scalars(8, 4242)); co[32:64] = bytes(32)
+    _run_stateful_sumcheck(ctx, ol, 1 << 15, 5, 3, 7900, bytes(co))
+    _run_stateful_sumcheck(ctx, ol, 1 << 6, 5, 3, 7910, bytes(co))
+    one = (1).to_bytes(32, "little"); top = (pr.R - 1).to_bytes(32, "little")
+    _run_stateful_sumcheck(ctx, ol, 1 << 15, 3, 1, 7920, one + top + one + top)              # coefficients 1 and r - 1
+    for var in ("SBN_SC_NO_COMB", "SBN_SC_NO_COMB_KERNEL"):
+        os.environ[var] = "1"
+        try:
+            _run_stateful_sumcheck(ctx, ol, 1 << 16, 4, 2, 7930)
+        finally:
+            del os.environ[var]
+
+
+def test_stateful_sumcheck_errors(ctx, sbn, pr):
+    a, b, c2 = (ctx.table_upload(rand_scalars(8, s)) for s in (1, 2, 3))
+    short = ctx.table_upload(rand_scalars(4, 4))
+    with pytest.raises(sbn.SbnError):
+        ctx.sumcheck_begin([a], [short], c2, [], [], [], rand_scalars(1, 5))                 # lengths differ
+    with pytest.raises(sbn.SbnError):
+        ctx.sumcheck_begin([a], [b], c2, [], [], [], pr.R.to_bytes(32, "little"))          # non-canonical coefficient
+    st, _ = ctx.sumcheck_begin([a], [b], c2, [], [], [], rand_scalars(1, 5))
+    with pytest.raises(sbn.SbnError):
+        st.finish()                                                                         # variables left
+    with pytest.raises(sbn.SbnError):
+        st.round(pr.R.to_bytes(32, "little"))                                               # non-canonical challenge
+    for j in range(3):
+        st.round(rand_scalars(1, 10 + j))
+    with pytest.raises(sbn.SbnError):
+        st.round(rand_scalars(1, 20))                                                       # no variable left
+    assert len(st.finish()) == 3
+    st.free()
+    for t in (a, b, c2, short):
+        t.free()
+
+
+def test_stateful_sumcheck_keyless_layer0(ctx, ol):
+    """the ops product-circuit layer-0 sumcheck at keyless size (12 par + 6 seq, tables of 2^21 uniform Fr): all 21 combined round
+    values and the 43 final claims against the oracle"""
+    _run_stateful_sumcheck(ctx, ol, 1 << 21, 12, 6, 9900)

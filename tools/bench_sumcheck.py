@@ -70,12 +70,32 @@ def main():
                 times.append(dt)
         res[mode] = {"ms_per_sumcheck": round(1e3 * sum(times) / len(times), 3), "finals": [f.hex()[:16] for f in finals],
                      "kernels_ms_total": {k: round(v[0], 3) for k, v in prof.items()}, "kernels_launches": {k: v[1] for k, v in prof.items()}}
+    # the stateful form (sbn_sumcheck_*): what crosses the boundary per round is the coeffs-combined triple (sumcheck.rs:269-271)
+    coeffs = b"".join(((0x9E3779B97F4A7C15 * (i + 1)) % R_MOD).to_bytes(32, "little") for i in range(NPAR + NSEQ))
+    times = []
+    for rep in range(reps + 1):
+        ts, As, Bs, Cs = fresh()
+        ctx.prof_enable(True); ctx.prof_reset()
+        ctx.sync(); t0 = time.perf_counter()
+        st, ev = ctx.sumcheck_begin(As[:NPAR], Bs[:NPAR], Cs[0], As[NPAR:], Bs[NPAR:], Cs[NPAR:], coeffs)
+        for rnd in range(logn):
+            ev = st.round(challenge(ev + bytes([rnd])))
+        fin = st.finish()
+        ctx.sync(); dt = time.perf_counter() - t0
+        prof = ctx.prof_get(); ctx.prof_enable(False)
+        st.free()
+        for t in ts:
+            t.free()
+        if rep:
+            times.append(dt)
+    res["stateful"] = {"ms_per_sumcheck": round(1e3 * sum(times) / len(times), 3), "finals": [f.hex()[:16] for f in fin[:3]],
+                       "kernels_ms_total": {k: round(v[0], 3) for k, v in prof.items()}, "kernels_launches": {k: v[1] for k, v in prof.items()}}
     assert res["separate"]["finals"] == res["fused"]["finals"], "fused and separate rounds disagree"
     table_bytes = ntab * n * 32
     # sum over rounds of live bytes: 2 * table_bytes (geometric)
     alg_sep = 2 * table_bytes * (1 + 1 + 0.5)          # eval read + bind read + bind write
     alg_fused = table_bytes + 2 * table_bytes * (1 + 0.5) - table_bytes * 0  # first eval + fused rounds (read + half write) over all rounds
-    for mode, alg in (("separate", alg_sep), ("fused", alg_fused)):
+    for mode, alg in (("separate", alg_sep), ("fused", alg_fused), ("stateful", alg_fused)):
         ms = res[mode]["ms_per_sumcheck"]
         res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
         res[mode]["GBps_vs_8000"] = round(alg / (ms * 1e-3) / 1e9, 1)
@@ -88,6 +108,11 @@ def main():
     fused_ms = stream_ms + kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)
     res["fused"]["kernel_only_rounds_ms"] = round(fused_ms, 3)
     res["fused"]["kernel_only_rounds_GBps"] = round(2 * table_bytes * 1.5 / (fused_ms * 1e-3) / 1e9, 1) if fused_ms else None
+    ks = res["stateful"]["kernels_ms_total"]
+    st_stream = ks.get("k_sc_comb_bind_eval", 0.0) + ks.get("k_sc_bind_eval_cubic_stream", 0.0) + ks.get("k_bind_oop", 0.0)
+    if st_stream and npf:
+        res["stateful"]["streaming_rounds_ms"] = round(st_stream, 3)
+        res["stateful"]["streaming_rounds_GBps"] = round(table_bytes * 1.5 * sum(0.5 ** j for j in range(npf)) / (st_stream * 1e-3) / 1e9, 1)
     res["env"] = {k: v for k, v in os.environ.items() if k.startswith("SBN_")}
     print(json.dumps({"workload": f"batched cubic sumcheck, {NPAR} par + {NSEQ} seq instances, tables of 2^{logn}, {logn} rounds, {round(table_bytes / 2**30, 2)} GiB in round 0", **res}))
     ctx.close()

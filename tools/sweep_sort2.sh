@@ -13,7 +13,7 @@ LOGN=24 STEPS=5; TAG="auto" run; TAG="lo=10" SBN_SORT2_LO=10 run; TAG="c=19" SBN
 LOGN=23 STEPS=5; TAG="auto" run; TAG="c=18" SBN_MSM_C=18 run; TAG="c=20" SBN_MSM_C=20 run
 LOGN=22 STEPS=8; TAG="auto" run; TAG="lo=9" SBN_SORT2_LO=9 run; TAG="c=18" SBN_MSM_C=18 run
 LOGN=21 STEPS=8; TAG="auto" run; TAG="c=16" SBN_MSM_C=16 run
-LOGN=20 STEPS=10; TAG="one-level (default)" run; TAG="two-level" SBN_SORT2_MIN=1024 run; TAG="two-level c=16" SBN_SORT2_MIN=1024 SBN_MSM_C=16 run; TAG="two-level c=17" SBN_SORT2_MIN=1024 SBN_MSM_C=17 run
+LOGN=20 STEPS=10; TAG="one-level" SBN_SORT2_MIN=0 run; TAG="two-level (default from 2^20)" run; TAG="two-level c=16" SBN_SORT2_MIN=1024 SBN_MSM_C=16 run; TAG="two-level c=17" SBN_SORT2_MIN=1024 SBN_MSM_C=17 run
 LOGN=19 STEPS=10; TAG="one-level (default)" run; TAG="two-level" SBN_SORT2_MIN=1024 run
 LOGN=18 STEPS=10; TAG="one-level (default)" run; TAG="two-level" SBN_SORT2_MIN=1024 run
 exit 0
