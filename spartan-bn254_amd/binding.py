@@ -67,6 +67,44 @@ def lib():
     return _LIB
 
 
+HARNESS_STAGES = ["r1cs_sat_proof", "eq_evals", "derefs_computation", "derefs_commitment", "network_construction", "network_proof",
+                  "sub_witness_commit", "sub_phase1_sumcheck", "sub_phase2_sumcheck", "sub_witness_opening", "sub_ops_sumchecks", "sub_mem_sumchecks",
+                  "sub_evaluations", "sub_openings"]
+
+
+class HarnessParams(C.Structure):
+    _fields_ = [("log_ops", C.c_int32), ("log_mem", C.c_int32), ("log_cons", C.c_int32), ("stateful_sumcheck", C.c_int32),
+                ("lookup_bytes_sat", C.c_uint64), ("lookup_bytes_eval", C.c_uint64), ("seed", C.c_uint64), ("rounds_out", C.c_uint32 * 4)]
+
+
+_HARNESS = None
+
+
+def harness_lib():
+    """libsbn_prove_harness.so: the compiled caller of the C ABI (harness/prove_stages.cpp)"""
+    global _HARNESS
+    if _HARNESS is None:
+        lib()                                                  # the product library first (the harness links against it)
+        p = os.path.join(_HERE, "libsbn_prove_harness.so")
+        if not os.path.exists(p):
+            raise SbnError(f"{p} is missing: run `make -C {_HERE}`")
+        _HARNESS = C.CDLL(p)
+    return _HARNESS
+
+
+def harness_prove(ctx, log_ops, log_mem, log_cons, stateful=True, lookup_bytes_sat=0, lookup_bytes_eval=0, seed=1, trace_cap=0):
+    """one keyless-shaped prove's device-side stages from compiled code -> (stage_ms dict, digest, trace bytes, rounds dict)"""
+    prm = HarnessParams(log_ops, log_mem, log_cons, 1 if stateful else 0, lookup_bytes_sat, lookup_bytes_eval, seed)
+    ms = (C.c_double * 16)(); dig = (C.c_uint8 * 32)(); err = C.create_string_buffer(512)
+    tr = (C.c_uint8 * trace_cap)() if trace_cap else None; tl = C.c_size_t(0)
+    rc = harness_lib().sbn_harness_prove(ctx.h, C.byref(prm), ms, dig, tr, C.c_size_t(trace_cap), C.byref(tl), err, C.c_size_t(512))
+    if rc:
+        raise SbnError("sbn_harness_prove: " + err.value.decode())
+    stages = {n: ms[i] for i, n in enumerate(HARNESS_STAGES)}
+    rounds = {"sumcheck_rounds_ops": prm.rounds_out[0], "sumcheck_rounds_mem": prm.rounds_out[1], "bullet_rounds": prm.rounds_out[2], "layers": prm.rounds_out[3]}
+    return stages, bytes(dig), (bytes(tr[:tl.value]) if trace_cap else b""), rounds
+
+
 def _ptr(x):
     """host bytes-like -> char pointer; None -> NULL"""
     if x is None:

@@ -1,0 +1,395 @@
+// prove_stages.cpp — a COMPILED caller of libsbn254_hip.so that issues, stage by stage, the device-side work of one keyless-SHAPED
+// SNARK::prove (Hyrax mode) through the C ABI only (include/sbn254.h), the way the Rust shim of INTEGRATION.md does.
+//
+// Why it exists: the reference's own benchmark (examples/keyless_benchmark.rs:171-238) times the stages of SNARK::prove; that binary
+// cannot be built here (no Rust toolchain), and a Python-driven loop pays ~40 us of interpreter per sumcheck round (441 rounds per
+// prove).  This harness is what a compiled host sees: per round one ABI call, a UniPoly interpolation, a hash, the next call.
+//
+// Stage names follow keyless_benchmark.rs: "R1CS sat proof" (:171-183; r1csproof.rs:241-420: witness commitment, phase-1 and phase-2
+// sumchecks, witness opening), "EqPolynomial evaluation" (:197-203), "Derefs computation" (:205-208), "Derefs commitment" (:210-223),
+// "Network construction" (:225-229), "Network proof" (:231-236; sparse_mlpoly_full.rs:1546-1575: layered batched cubic sumchecks of
+// the ops and mem product circuits, 23 evaluations, three Hyrax openings).  "Instance evaluations" (:185-188) is sparse host work
+// with no device counterpart and is not here, nor are the Sigma-protocol steps of the ZK sumchecks and the Merlin transcript
+// (a SHA3 chain stands in for it: strictly sequential either way).
+//
+// Inputs are synthetic with the keyless shapes: tables from sbn_scalars_synthetic (uniform Fr), addresses and
+// timestamps from SplitMix64.  With a trace buffer every value the stand-in transcript absorbs or squeezes is recorded, so that
+// tests/harness_model.py can replay the run against the CPU oracle (tests/test_gpu_harness.py, bench.py's parity gate).
+#include "../../include/sbn254.h"
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ---- SHA3-256 (FIPS 202), for the stand-in transcript ------------------------------------------------------------------------
+const uint64_t KRC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull, 0x0000000080000001ull,
+                          0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+                          0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull,
+                          0x000000000000800aull, 0x800000008000000aull, 0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+const int KROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+inline uint64_t rol(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+void keccak_f(uint64_t s[25]) {
+  for (int rnd = 0; rnd < 24; rnd++) {
+    uint64_t c[5], d[5], b[25];
+    for (int x = 0; x < 5; x++) c[x] = s[x] ^ s[x + 5] ^ s[x + 10] ^ s[x + 15] ^ s[x + 20];
+    for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+    for (int i = 0; i < 25; i++) s[i] ^= d[i % 5];
+    for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(s[x + 5 * y], KROT[x + 5 * y]);
+    for (int y = 0; y < 5; y++) for (int x = 0; x < 5; x++) s[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+    s[0] ^= KRC[rnd];
+  }
+}
+void sha3_256(const uint8_t* in, size_t len, uint8_t out[32]) {
+  uint64_t s[25] = {0};
+  const size_t rate = 136;
+  while (len >= rate) { for (size_t i = 0; i < rate / 8; i++) { uint64_t w; memcpy(&w, in + 8 * i, 8); s[i] ^= w; } keccak_f(s); in += rate; len -= rate; }
+  uint8_t blk[136] = {0}; memcpy(blk, in, len); blk[len] ^= 0x06; blk[rate - 1] ^= 0x80;
+  for (size_t i = 0; i < rate / 8; i++) { uint64_t w; memcpy(&w, blk + 8 * i, 8); s[i] ^= w; }
+  keccak_f(s);
+  memcpy(out, s, 32);
+}
+
+// ---- Fr on the host (what the Rust side has from ark-ff): Montgomery CIOS, for u^-1 of the bullet rounds and the claim updates ----
+typedef unsigned __int128 u128;
+struct El { uint64_t v[4]; };
+const uint64_t RP[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+const uint64_t RR2[4] = {0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull};
+const uint64_t RNINV = 0xc2e1f593efffffffull;
+bool geq_r(const uint64_t a[4]) { for (int i = 3; i >= 0; i--) { if (a[i] > RP[i]) return true; if (a[i] < RP[i]) return false; } return true; }
+void sub_r(uint64_t a[4]) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - RP[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } }
+El mmul(const El& a, const El& b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < 4; j++) { u128 s = (u128)a.v[j] * b.v[i] + t[j] + c; t[j] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    u128 s = (u128)t[4] + c; t[4] = (uint64_t)s; t[5] = (uint64_t)(s >> 64);
+    const uint64_t m = t[0] * RNINV;
+    s = (u128)m * RP[0] + t[0]; c = (uint64_t)(s >> 64);
+    for (int j = 1; j < 4; j++) { s = (u128)m * RP[j] + t[j] + c; t[j - 1] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    s = (u128)t[4] + c; t[3] = (uint64_t)s; t[4] = t[5] + (uint64_t)(s >> 64);
+  }
+  El r = {{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq_r(r.v)) sub_r(r.v);
+  return r;
+}
+El fr_inv(const El& a) {          // canonical in, canonical out
+  El r2; memcpy(r2.v, RR2, 32);
+  const El am = mmul(a, r2);
+  El one = {{1, 0, 0, 0}}, acc = mmul(one, r2);
+  const uint64_t e[4] = {RP[0] - 2, RP[1], RP[2], RP[3]};
+  for (int i = 255; i >= 0; i--) { acc = mmul(acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mmul(acc, am); }
+  return mmul(acc, one);
+}
+// 32 hash bytes -> a canonical scalar: the top two bits cut, minus r when still >= r (uniform enough for a stand-in)
+void reduce_to_fr(uint8_t b[32]) { uint64_t v[4]; memcpy(v, b, 32); v[3] &= 0x3fffffffffffffffull; if (geq_r(v)) sub_r(v); memcpy(b, v, 32); }
+
+uint64_t splitmix(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
+
+struct Fail { std::string msg; };
+
+}  // namespace
+
+extern "C" {
+
+enum { ST_R1CS_SAT = 0, ST_EQ = 1, ST_DEREFS = 2, ST_DEREFS_COMMIT = 3, ST_NETWORK = 4, ST_NETWORK_PROOF = 5,
+       ST_SUB_WITNESS_COMMIT = 6, ST_SUB_PHASE1 = 7, ST_SUB_PHASE2 = 8, ST_SUB_WITNESS_OPEN = 9, ST_SUB_OPS_SUMCHECKS = 10, ST_SUB_MEM_SUMCHECKS = 11,
+       ST_SUB_EVALUATIONS = 12, ST_SUB_OPENINGS = 13, ST_COUNT = 16 };
+
+struct sbn_harness_params {
+  int32_t log_ops, log_mem, log_cons;      // keyless: 22, 21, 20
+  int32_t stateful_sumcheck;               // 1: sbn_sumcheck_* for the product-circuit sumchecks, 0: the per-instance calls + host combination
+  uint64_t lookup_bytes_sat, lookup_bytes_eval;   // sbn_bases_precompute budgets of the two generator sets (0: bucket method)
+  uint64_t seed;
+  uint32_t rounds_out[4];                  // out: sumcheck rounds (ops, mem), bullet rounds, layers
+};
+
+struct Harness {
+  sbn_ctx* ctx; const sbn_harness_params* p;
+  uint8_t h[32];                            // the stand-in transcript's state
+  uint8_t* trace; size_t trace_cap, trace_len; bool trace_overflow;
+  double ms[ST_COUNT];
+  std::vector<uint8_t> scratch;
+
+  void chk(int rc, const char* what) { if (rc) { Fail f; f.msg = std::string(what) + ": " + sbn_last_error(ctx); throw f; } }
+  void rec(uint32_t tag, const uint8_t* d, size_t n) {
+    if (!trace) return;
+    if (trace_len + 8 + n > trace_cap) { trace_overflow = true; return; }
+    const uint32_t hdr[2] = {tag, (uint32_t)n}; memcpy(trace + trace_len, hdr, 8); memcpy(trace + trace_len + 8, d, n); trace_len += 8 + n;
+  }
+  // absorb: h <- SHA3(h || data); every absorbed value is also a trace record (tag identifies the stage output)
+  void absorb(uint32_t tag, const uint8_t* d, size_t n) {
+    scratch.resize(32 + n); memcpy(scratch.data(), h, 32); memcpy(scratch.data() + 32, d, n);
+    sha3_256(scratch.data(), 32 + n, h); rec(tag, d, n);
+  }
+  void challenge(uint8_t out[32]) {
+    uint8_t in[33]; memcpy(in, h, 32); in[32] = 0x63;
+    sha3_256(in, 33, h); memcpy(out, h, 32); reduce_to_fr(out); rec(0xC0, out, 32);
+  }
+  std::vector<uint8_t> cvec(size_t k) { std::vector<uint8_t> v(32 * k); for (size_t i = 0; i < k; i++) challenge(v.data() + 32 * i); return v; }
+
+  struct Timer { Harness* H; int a, b; std::chrono::steady_clock::time_point t0;
+    Timer(Harness* H_, int a_, int b_ = -1) : H(H_), a(a_), b(b_) { sbn_ctx_sync(H->ctx); t0 = std::chrono::steady_clock::now(); }
+    ~Timer() { sbn_ctx_sync(H->ctx); const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); H->ms[a] += d; if (b >= 0) H->ms[b] += d; } };
+
+  sbn_table* synth_table(size_t n, uint64_t stream) {
+    void* d = nullptr; chk(sbn_dev_alloc(ctx, n * 32, &d), "dev_alloc");
+    chk(sbn_scalars_synthetic(ctx, p->seed + stream, 0, n, d), "scalars_synthetic");
+    sbn_table* t = nullptr; chk(sbn_table_from_dev(ctx, d, n, 0, &t), "table_from_dev");
+    chk(sbn_dev_free(ctx, d), "dev_free");
+    return t;
+  }
+  void* upload_u32(const std::vector<uint32_t>& v) { void* d = nullptr; chk(sbn_dev_alloc(ctx, v.size() * 4, &d), "dev_alloc"); chk(sbn_dev_upload(ctx, d, v.data(), v.size() * 4), "dev_upload"); return d; }
+
+  // PolyEvalProof::prove (hyrax.rs:65-116): L, R = eq tables of the two halves of the point, LZ = poly.bound(L) (hyrax.rs:311-324), then
+  // DotProductProofLog's bullet reduction over (LZ, R) (nizk/mod.rs:439-522, nizk/bullet.rs:41-126)
+  void opening(const sbn_table* Z, size_t log_l, size_t log_r, const sbn_bases* G, int sub_stage, int stage) {
+    const std::vector<uint8_t> rl = cvec(log_l), rr = cvec(log_r);
+    sbn_table *Lv = nullptr, *Rv = nullptr, *LZ = nullptr;
+    sbn_bullet* st = nullptr;
+    {
+      Timer t(this, sub_stage, stage);
+      chk(sbn_eq_evals(ctx, rl.data(), log_l, &Lv), "eq_evals L"); chk(sbn_eq_evals(ctx, rr.data(), log_r, &Rv), "eq_evals R");
+      chk(sbn_table_bound(ctx, Z, Lv, &LZ), "table_bound");
+      uint8_t zr[32]; chk(sbn_table_dot(ctx, LZ, Rv, zr), "table_dot"); absorb(0x40, zr, 32);            // the claimed evaluation <LZ, R> = Z(r)
+      uint8_t Q[64] = {0}; Q[0] = 1; Q[32] = 2;
+      uint8_t blind[32]; challenge(blind);
+      uint8_t gamma[64]; int ginf = 0;
+      chk(sbn_bullet_begin(ctx, G, Q, LZ, Rv, blind, gamma, &ginf, &st), "bullet_begin"); absorb(0x41, gamma, 64);
+      for (size_t rnd = 0; rnd < log_r; rnd++) {
+        uint8_t bl[32], br[32]; challenge(bl); challenge(br);
+        uint8_t LR[128], cl[32], cr[32]; int li = 0, ri = 0;
+        chk(sbn_bullet_cross(ctx, st, bl, br, LR, &li, LR + 64, &ri, cl, cr), "bullet_cross"); absorb(0x42, LR, 128);
+        uint8_t u[32]; challenge(u);
+        El ue; memcpy(ue.v, u, 32); const El ui = fr_inv(ue);
+        chk(sbn_bullet_fold(ctx, st, u, (const uint8_t*)ui.v), "bullet_fold");
+        p_rounds_bullet++;
+      }
+      uint8_t fin[128]; int gi = 0;
+      chk(sbn_bullet_finish(ctx, st, fin, fin + 32, fin + 64, &gi), "bullet_finish"); absorb(0x43, fin, 128);
+    }
+    sbn_bullet_free(ctx, st); sbn_table_free(ctx, Lv); sbn_table_free(ctx, Rv); sbn_table_free(ctx, LZ);
+  }
+  uint32_t p_rounds_bullet = 0, p_rounds_ops = 0, p_rounds_mem = 0, p_layers = 0;
+
+  // one sumcheck of `kind` over the given tables with the per-round calls of the ABI: 0 = r1cs (4 tables), 1 = quad (2 tables)
+  void zk_sumcheck(int kind, std::vector<sbn_table*>& T) {
+    uint8_t ev[96] = {0}; const size_t ne = kind == 0 ? 96 : 64;
+    if (kind == 0) chk(sbn_sc_eval_r1cs(ctx, T[0], T[1], T[2], T[3], ev), "sc_eval_r1cs"); else chk(sbn_sc_eval_quad(ctx, T[0], T[1], ev), "sc_eval_quad");
+    for (size_t n = sbn_table_len(T[0]); n >= 2; n /= 2) {
+      absorb(kind == 0 ? 0x10 : 0x11, ev, ne);
+      uint8_t r[32]; challenge(r);
+      if (n >= 4) { if (kind == 0) chk(sbn_sc_bind_eval_r1cs(ctx, T[0], T[1], T[2], T[3], r, ev), "sc_bind_eval_r1cs"); else chk(sbn_sc_bind_eval_quad(ctx, T[0], T[1], r, ev), "sc_bind_eval_quad"); }
+      else chk(sbn_bind_top_many(ctx, T.data(), T.size(), r), "bind_top_many");
+    }
+    std::vector<uint8_t> fin(32 * T.size());
+    for (size_t i = 0; i < T.size(); i++) chk(sbn_table_read0(ctx, T[i], fin.data() + 32 * i), "read0");
+    absorb(0x12, fin.data(), fin.size());
+  }
+
+  // ProductCircuitEvalProofBatched::prove (product_tree.rs:251-392): layer by layer from the top, per layer one batched cubic sumcheck
+  // (prove_cubic_batched, sumcheck.rs:165-330) over the halves of every circuit's layer + (at layer 0) the dot-product circuits
+  uint32_t layered(std::vector<std::vector<sbn_table*>>& circ, std::vector<sbn_table*>* dotp) {
+    uint32_t rounds = 0;
+    const size_t nc = circ.size(), nl = circ[0].size();
+    for (size_t lay = nl; lay-- > 0;) {
+      p_layers++;
+      std::vector<sbn_table*> A(nc), B(nc);
+      for (size_t i = 0; i < nc; i++) chk(sbn_table_halves(ctx, circ[i][lay], &A[i], &B[i]), "table_halves");
+      const size_t half = sbn_table_len(A[0]); size_t k = 0; while (((size_t)1 << k) < half) k++;
+      const std::vector<uint8_t> rand = cvec(k);                      // stands in for the accumulated `rand` (product_tree.rs:271)
+      sbn_table* C = nullptr; chk(sbn_eq_evals(ctx, rand.data(), k, &C), "eq_evals C");
+      std::vector<sbn_table*> As, Bs, Cs;
+      if (lay == 0 && dotp) { const size_t ns = dotp->size() / 3; for (size_t j = 0; j < ns; j++) { As.push_back((*dotp)[j]); Bs.push_back((*dotp)[ns + j]); Cs.push_back((*dotp)[2 * ns + j]); } }
+      const size_t ninst = nc + As.size();
+      const std::vector<uint8_t> coeffs = cvec(ninst);                 // transcript.challenge_vector(b"rand_coeffs_next_layer") (product_tree.rs:319)
+      if (half >= 2) {
+        uint8_t ev[96];
+        if (p->stateful_sumcheck) {
+          sbn_sumcheck* st = nullptr;
+          chk(sbn_sumcheck_begin(ctx, A.data(), B.data(), C, nc, As.data(), Bs.data(), Cs.data(), As.size(), coeffs.data(), ev, &st), "sumcheck_begin");
+          for (size_t n = half; n >= 2; n /= 2) {
+            absorb(0x20, ev, 96); uint8_t r[32]; challenge(r); rounds++;
+            chk(sbn_sumcheck_round(ctx, st, r, ev), "sumcheck_round");
+          }
+          std::vector<uint8_t> fin(32 * (2 * nc + 1 + 3 * As.size()));
+          chk(sbn_sumcheck_finish(ctx, st, fin.data()), "sumcheck_finish"); absorb(0x21, fin.data(), fin.size());
+          sbn_sumcheck_free(ctx, st);
+        } else {
+          // the per-instance calls: count x (e0, e2, e3) back per round, combined with coeffs here (sumcheck.rs:269-271)
+          std::vector<sbn_table*> a = A, b = B, c(nc, C);
+          a.insert(a.end(), As.begin(), As.end()); b.insert(b.end(), Bs.begin(), Bs.end()); c.insert(c.end(), Cs.begin(), Cs.end());
+          std::vector<uint8_t> evs(96 * ninst);
+          El r2; memcpy(r2.v, RR2, 32);
+          std::vector<El> cm(ninst); for (size_t i = 0; i < ninst; i++) { El e; memcpy(e.v, coeffs.data() + 32 * i, 32); cm[i] = mmul(e, r2); }
+          auto combine = [&]() { for (int t = 0; t < 3; t++) { El acc = {{0, 0, 0, 0}}; for (size_t i = 0; i < ninst; i++) { El x; memcpy(x.v, evs.data() + 96 * i + 32 * t, 32); x = mmul(cm[i], x);
+                                   uint64_t cy = 0; for (int q = 0; q < 4; q++) { u128 s = (u128)acc.v[q] + x.v[q] + cy; acc.v[q] = (uint64_t)s; cy = (uint64_t)(s >> 64); } if (cy || geq_r(acc.v)) sub_r(acc.v); } memcpy(ev + 32 * t, acc.v, 32); } };
+          chk(sbn_sc_eval_cubic_batched(ctx, a.data(), b.data(), c.data(), ninst, evs.data()), "sc_eval_cubic_batched"); combine();
+          std::vector<sbn_table*> all = A; all.insert(all.end(), B.begin(), B.end()); all.push_back(C);
+          all.insert(all.end(), As.begin(), As.end()); all.insert(all.end(), Bs.begin(), Bs.end()); all.insert(all.end(), Cs.begin(), Cs.end());
+          for (size_t n = half; n >= 2; n /= 2) {
+            absorb(0x20, ev, 96); uint8_t r[32]; challenge(r); rounds++;
+            if (n >= 4) { chk(sbn_sc_bind_eval_cubic_batched(ctx, a.data(), b.data(), c.data(), ninst, r, evs.data()), "sc_bind_eval_cubic_batched"); combine(); }
+            else chk(sbn_bind_top_many(ctx, all.data(), all.size(), r), "bind_top_many");
+          }
+          std::vector<uint8_t> fin(32 * all.size());
+          for (size_t i = 0; i < all.size(); i++) chk(sbn_table_read0(ctx, all[i], fin.data() + 32 * i), "read0");
+          absorb(0x21, fin.data(), fin.size());
+        }
+      }
+      for (size_t i = 0; i < nc; i++) { sbn_table_free(ctx, A[i]); sbn_table_free(ctx, B[i]); }
+      sbn_table_free(ctx, C);
+    }
+    return rounds;
+  }
+
+  void run() {
+    const int LO = p->log_ops, LM = p->log_mem, LC = p->log_cons;
+    const size_t nops = (size_t)1 << LO, nmem = (size_t)1 << LM, ncons = (size_t)1 << LC;
+    // ---------------- per-circuit setup (not timed): generator sets, their window / lookup tables, address and timestamp arrays
+    const size_t wl = LC / 2, wr = LC - wl;
+    sbn_bases* gens_w = nullptr; chk(sbn_gens_new(ctx, (size_t)1 << wr, (const uint8_t*)"gens_r1cs_sat", 13, nullptr, &gens_w), "gens_new sat");
+    if (p->lookup_bytes_sat) chk(sbn_bases_precompute(ctx, gens_w, p->lookup_bytes_sat, nullptr), "precompute sat");
+    const size_t dl = (LO + 3) / 2, dr = LO + 3 - dl;
+    sbn_bases* gens_d = nullptr; chk(sbn_gens_new(ctx, (size_t)1 << dr, (const uint8_t*)"gens_r1cs_eval", 14, nullptr, &gens_d), "gens_new eval");
+    if (p->lookup_bytes_eval) chk(sbn_bases_precompute(ctx, gens_d, p->lookup_bytes_eval, nullptr), "precompute eval");
+    const size_t ol = (LO + 4) / 2, orr = LO + 4 - ol, ml = (LM + 1) / 2, mr = LM + 1 - ml;
+    sbn_bases* gens_o = gens_d; sbn_bases* gens_m = nullptr;
+    if (orr != dr) chk(sbn_gens_new(ctx, (size_t)1 << orr, (const uint8_t*)"gens_r1cs_eval", 14, nullptr, &gens_o), "gens_new ops");
+    chk(sbn_gens_new(ctx, (size_t)1 << mr, (const uint8_t*)"gens_r1cs_eval", 14, nullptr, &gens_m), "gens_new mem");
+    std::vector<void*> d_addr(6), d_rts(6), d_ats(2);
+    for (int k = 0; k < 6; k++) {
+      std::vector<uint32_t> a(nops), ts(nops);
+      const size_t real = (size_t)((double)nops * 0.57);                  // ~43 % padded ops read cell 0 (sparse_mlpoly_full.rs:89-101)
+      for (size_t i = 0; i < nops; i++) { const uint64_t x = splitmix(p->seed * 1000003ull + ((uint64_t)k << 40) + i); a[i] = i < real ? (uint32_t)(x % (nmem / 2)) : 0u; ts[i] = (uint32_t)((x >> 40) % 64); }
+      d_addr[k] = upload_u32(a); d_rts[k] = upload_u32(ts);
+    }
+    for (int s = 0; s < 2; s++) { std::vector<uint32_t> ts(nmem); for (size_t i = 0; i < nmem; i++) ts[i] = (uint32_t)(splitmix(p->seed * 7919ull + ((uint64_t)(s + 8) << 40) + i) % 64); d_ats[s] = upload_u32(ts); }
+    sbn_table* z = synth_table(ncons, 1);
+    {   // the first commit on a generator set builds its window table: setup
+      std::vector<uint8_t> o(64 << wl); chk(sbn_commit_table(ctx, gens_w, z, nullptr, (size_t)1 << wl, (size_t)1 << wr, o.data(), nullptr), "warm commit");
+    }
+
+    // ---------------- R1CS sat proof (keyless_benchmark.rs:171-183)
+    {
+      const std::vector<uint8_t> blinds = cvec((size_t)1 << wl);            // (random tape stand-in)
+      std::vector<uint8_t> C(64 << wl), Cc(32 << wl);
+      { Timer t(this, ST_SUB_WITNESS_COMMIT, ST_R1CS_SAT);
+        chk(sbn_commit_table(ctx, gens_w, z, blinds.data(), (size_t)1 << wl, (size_t)1 << wr, C.data(), nullptr), "witness commit");
+        chk(sbn_g1_compress(C.data(), (size_t)1 << wl, Cc.data()), "compress"); }
+      absorb(0x01, Cc.data(), Cc.size());
+      const std::vector<uint8_t> rtau = cvec(LC);
+      std::vector<sbn_table*> T(4);
+      T[1] = synth_table(ncons, 2); T[2] = synth_table(ncons, 3); T[3] = synth_table(ncons, 4);
+      { Timer t(this, ST_SUB_PHASE1, ST_R1CS_SAT); chk(sbn_eq_evals(ctx, rtau.data(), LC, &T[0]), "eq tau"); zk_sumcheck(0, T); }
+      for (sbn_table* x : T) sbn_table_free(ctx, x);
+      std::vector<sbn_table*> U = {synth_table(2 * ncons, 5), synth_table(2 * ncons, 6)};
+      { Timer t(this, ST_SUB_PHASE2, ST_R1CS_SAT); zk_sumcheck(1, U); }
+      for (sbn_table* x : U) sbn_table_free(ctx, x);
+      opening(z, wl, wr, gens_w, ST_SUB_WITNESS_OPEN, ST_R1CS_SAT);
+    }
+    sbn_table_free(ctx, z);
+
+    // ---------------- EqPolynomial evaluation, Derefs computation, Derefs commitment (keyless_benchmark.rs:197-223)
+    const std::vector<uint8_t> rx = cvec(LM), ry = cvec(LM);
+    sbn_table *mem_rx = nullptr, *mem_ry = nullptr, *comb = nullptr;
+    { Timer t(this, ST_EQ); chk(sbn_eq_evals(ctx, rx.data(), LM, &mem_rx), "eq rx"); chk(sbn_eq_evals(ctx, ry.data(), LM, &mem_ry), "eq ry"); }
+    {
+      const sbn_table* mems[6] = {mem_rx, mem_rx, mem_rx, mem_ry, mem_ry, mem_ry};
+      Timer t(this, ST_DEREFS); chk(sbn_gather_merge(ctx, mems, d_addr.data(), 6, nops, &comb), "gather_merge");
+    }
+    {
+      std::vector<uint8_t> o(64 << dl); chk(sbn_commit_table(ctx, gens_d, comb, nullptr, (size_t)1 << dl, (size_t)1 << dr, o.data(), nullptr), "warm commit");   // window table: setup
+      std::vector<uint8_t> C(64 << dl), Cc(32 << dl);
+      { Timer t(this, ST_DEREFS_COMMIT);
+        chk(sbn_commit_table(ctx, gens_d, comb, nullptr, (size_t)1 << dl, (size_t)1 << dr, C.data(), nullptr), "derefs commit");
+        chk(sbn_g1_compress(C.data(), (size_t)1 << dl, Cc.data()), "compress"); }
+      absorb(0x02, Cc.data(), Cc.size());
+    }
+
+    // ---------------- Network construction (keyless_benchmark.rs:225-229; sparse_mlpoly_full.rs:745-796, product_tree.rs:39-57)
+    std::vector<std::vector<sbn_table*>> ops_circ, mem_circ;
+    {
+      uint8_t g[32], tau[32]; challenge(g); challenge(tau);               // transcript.challenge_vector(b"challenge_r_hash", 2)
+      Timer t(this, ST_NETWORK);
+      for (int side = 0; side < 2; side++) {
+        const sbn_table* mem = side ? mem_ry : mem_rx;
+        sbn_table* x = nullptr;
+        chk(sbn_hash_layer(ctx, nullptr, mem, nullptr, 0, g, tau, &x), "hash init"); mem_circ.push_back({x});
+        chk(sbn_hash_layer(ctx, nullptr, mem, d_ats[side], 0, g, tau, &x), "hash audit"); mem_circ.push_back({x});
+        for (int i = 0; i < 3; i++) {
+          const int k = 3 * side + i;
+          sbn_table* val = nullptr; const sbn_table* m1[1] = {mem}; const void* a1[1] = {d_addr[k]};
+          chk(sbn_gather_merge(ctx, m1, a1, 1, nops, &val), "gather val");
+          chk(sbn_hash_layer(ctx, d_addr[k], val, d_rts[k], 0, g, tau, &x), "hash read"); ops_circ.push_back({x});
+          chk(sbn_hash_layer(ctx, d_addr[k], val, d_rts[k], 1, g, tau, &x), "hash write"); ops_circ.push_back({x});
+          sbn_table_free(ctx, val);
+        }
+      }
+      std::vector<uint8_t> prods;
+      for (auto* grp : {&ops_circ, &mem_circ}) for (auto& c : *grp) {
+        sbn_table* layers[48]; size_t cnt = 0;
+        chk(sbn_product_circuit(ctx, c[0], layers, 48, &cnt), "product_circuit");
+        for (size_t j = 0; j + 1 < cnt; j++) c.push_back(layers[j]);
+        uint8_t top[32]; chk(sbn_table_read0(ctx, layers[cnt - 1], top), "read0 product"); prods.insert(prods.end(), top, top + 32);
+        sbn_table_free(ctx, layers[cnt - 1]);                             // the single-entry layer is the product itself (ProductCircuit::evaluate)
+      }
+      absorb(0x03, prods.data(), prods.size());                           // claim_row_eval_* / claim_col_eval_* (sparse_mlpoly_full.rs:1326-1345)
+    }
+
+    // ---------------- Network proof (keyless_benchmark.rs:231-236)
+    {
+      std::vector<sbn_table*> dotp;                                        // 6 dot-product circuits: left, right, weight halves (sparse_mlpoly_full.rs:1353-1372)
+      for (int j = 0; j < 18; j++) dotp.push_back(synth_table(nops / 2, 20 + j));
+      { Timer t(this, ST_SUB_OPS_SUMCHECKS, ST_NETWORK_PROOF); p_rounds_ops = layered(ops_circ, &dotp); }
+      { Timer t(this, ST_SUB_MEM_SUMCHECKS, ST_NETWORK_PROOF); p_rounds_mem = layered(mem_circ, nullptr); }
+      for (sbn_table* x : dotp) sbn_table_free(ctx, x);
+      for (auto* grp : {&ops_circ, &mem_circ}) for (auto& c : *grp) for (sbn_table* x : c) sbn_table_free(ctx, x);
+      // HashLayerProof::prove (sparse_mlpoly_full.rs:907-976): 21 polynomials at rand_ops, 2 at rand_mem
+      std::vector<sbn_table*> big = {synth_table(nops, 50), synth_table(nops, 51), synth_table(nops, 52)};
+      const std::vector<uint8_t> r_ops = cvec(LO), r_mem = cvec(LM);
+      {
+        Timer t(this, ST_SUB_EVALUATIONS, ST_NETWORK_PROOF);
+        const sbn_table* zs[21]; for (int i = 0; i < 21; i++) zs[i] = big[i % 3];
+        uint8_t ev[21 * 32]; chk(sbn_table_evaluate_many(ctx, zs, 21, r_ops.data(), LO, ev), "evaluate_many ops"); absorb(0x30, ev, sizeof ev);
+        const sbn_table* zm[2] = {mem_rx, mem_ry};
+        uint8_t em[64]; chk(sbn_table_evaluate_many(ctx, zm, 2, r_mem.data(), LM, em), "evaluate_many mem"); absorb(0x31, em, 64);
+      }
+      for (sbn_table* x : big) sbn_table_free(ctx, x);
+      opening(comb, dl, dr, gens_d, ST_SUB_OPENINGS, ST_NETWORK_PROOF);
+      sbn_table* comb_ops = synth_table((size_t)1 << (ol + orr), 60);
+      opening(comb_ops, ol, orr, gens_o, ST_SUB_OPENINGS, ST_NETWORK_PROOF);
+      sbn_table_free(ctx, comb_ops);
+      sbn_table* comb_mem = synth_table((size_t)1 << (ml + mr), 61);
+      opening(comb_mem, ml, mr, gens_m, ST_SUB_OPENINGS, ST_NETWORK_PROOF);
+      sbn_table_free(ctx, comb_mem);
+    }
+    sbn_table_free(ctx, comb); sbn_table_free(ctx, mem_rx); sbn_table_free(ctx, mem_ry);
+    for (void* d : d_addr) sbn_dev_free(ctx, d);
+    for (void* d : d_rts) sbn_dev_free(ctx, d);
+    for (void* d : d_ats) sbn_dev_free(ctx, d);
+    if (gens_o != gens_d) sbn_bases_free(ctx, gens_o);
+    sbn_bases_free(ctx, gens_m); sbn_bases_free(ctx, gens_d); sbn_bases_free(ctx, gens_w);
+  }
+};
+
+// stage_ms: ST_COUNT doubles; digest: the stand-in transcript's final state; trace (optional): every absorbed value and challenge as
+// (u32 tag, u32 length, bytes) records.  Returns 0, or -1 with the message in err.
+int sbn_harness_prove(sbn_ctx* ctx, sbn_harness_params* params, double* stage_ms, uint8_t digest[32], uint8_t* trace, size_t trace_cap, size_t* trace_len, char* err, size_t errlen) {
+  if (!ctx || !params || !stage_ms || !digest) return -1;
+  Harness H; H.ctx = ctx; H.p = params; memset(H.h, 0, 32); H.trace = trace; H.trace_cap = trace_cap; H.trace_len = 0; H.trace_overflow = false;
+  for (int i = 0; i < ST_COUNT; i++) H.ms[i] = 0;
+  try { H.run(); } catch (const Fail& f) { if (err && errlen) snprintf(err, errlen, "%s", f.msg.c_str()); return -1; }
+  if (H.trace_overflow) { if (err && errlen) snprintf(err, errlen, "trace buffer too small"); return -1; }
+  for (int i = 0; i < ST_COUNT; i++) stage_ms[i] = H.ms[i];
+  memcpy(digest, H.h, 32);
+  if (trace_len) *trace_len = H.trace_len;
+  params->rounds_out[0] = H.p_rounds_ops; params->rounds_out[1] = H.p_rounds_mem; params->rounds_out[2] = H.p_rounds_bullet; params->rounds_out[3] = H.p_layers;
+  return 0;
+}
+
+}  // extern "C"
