@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--rows", type=int, default=4096, help="hyrax: matrix rows")
     ap.add_argument("--cols", type=int, default=8192, help="hyrax: matrix columns")
     ap.add_argument("--inflight", type=int, default=6, help="headline: independent steps kept in flight on separate HIP streams (contexts); 1 = strictly serial")
-    ap.add_argument("--blocks", default="all", help="extra blocks: all | none | comma list of hyrax,sweep,sumcheck")
+    ap.add_argument("--blocks", default="all", help="extra blocks: all | none | comma list of hyrax,sweep,sumcheck,prove_stages")
     ap.add_argument("--sweep", default="22,24,26", help="msm_sweep sizes (log2) on one GPU")
     ap.add_argument("--strong-log-n", type=int, default=26, help="N > 1: log2 of the FIXED total size of the strong-scaling MSM (config 4)")
     ap.add_argument("--sc-log-n", type=int, default=21, help="sumcheck block: log2 of the table length")
@@ -199,7 +199,7 @@ def main():
     ctx = sbn.Context(dev_index)    # raises if the HIP library / device is missing: no fallback
     M = max(1, args.inflight)
     ctxs = [ctx] + [sbn.Context(dev_index) for _ in range(M - 1)]     # one HIP stream + workspace per step in flight
-    blocks = set() if args.blocks == "none" else ({"hyrax", "sweep", "sumcheck"} if args.blocks == "all" else set(args.blocks.split(",")))
+    blocks = set() if args.blocks == "none" else ({"hyrax", "sweep", "sumcheck", "prove_stages"} if args.blocks == "all" else set(args.blocks.split(",")))
 
     def barrier():
         if world > 1:
@@ -534,6 +534,13 @@ def main():
             line_extra["sumcheck"] = {"error": str(e)}
         torch.cuda.empty_cache()
 
+    if "prove_stages" in blocks and world == 1:
+        try:
+            line_extra["prove_stages"] = prove_stages_block(ctx, sbn, int(args.precompute_gb * (1 << 30)))
+        except sbn.SbnError as e:
+            line_extra["prove_stages"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         line = {"metric": "msm_points_per_s", "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -551,97 +558,174 @@ def main():
 
 def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
     """prove_cubic_batched, layer 0 of the ops product circuits (sumcheck.rs:165-330): 12 "par" instances sharing one C
-    table + 6 "seq" instances; fused bind+eval rounds.  Parity: round-0 sums of one par and one seq instance against the CPU
-    oracle, e0 + e1 = claim is implied by construction, and the fused rounds' final table values against the separate
-    eval / bind path on the same inputs."""
+    table + 6 "seq" instances, tables of 2^logn uniform Fr values.  Three drivers of the same rounds:
+      stateful  sbn_sumcheck_begin / round / finish: the coeffs-combined triple per round (what the transcript absorbs, :269-271), "par"
+                group on the combined kernels (one reduction per index for all instances, C factored out)   <- the reported path
+      fused     one sbn_sc_bind_eval_cubic_batched per round, 18 triples back per round (round 2's path)
+      separate  eval + bind launches (the reference's structure)
+    Parity: the stateful run's combined values of ALL rounds and its 43 final claims against the oracle's prove_cubic_batched loop on
+    the same tables; fused and separate must agree with each other on every final value and with the stateful finals."""
+    import numpy as np
     n = 1 << logn
     NPAR, NSEQ = 12, 6
     ntab = 2 * NPAR + 1 + 3 * NSEQ
+    coeffs = splitmix_scalars(NPAR + NSEQ, SEED + 77)
 
-    def fresh():
-        ts = []
+    def fresh(keep_host=False):
+        ts, host = [], []
         for k in range(ntab):
             x = torch.empty(32 * n, dtype=torch.uint8, device=dev)
             ctx.scalars_synthetic(SEED + 1000 + k, 0, n, x.data_ptr())
+            if keep_host:
+                torch.cuda.synchronize(); host.append(x.cpu().numpy())
             ts.append(ctx.table_from_dev(x.data_ptr(), n, 0)); del x
+        return ts, host
+
+    def split(ts):
         par_a, par_b, c_par = ts[:NPAR], ts[NPAR:2 * NPAR], ts[2 * NPAR]
         rest = ts[2 * NPAR + 1:]
-        seq_a, seq_b, seq_c = rest[:NSEQ], rest[NSEQ:2 * NSEQ], rest[2 * NSEQ:]
-        return ts, par_a + seq_a, par_b + seq_b, [c_par] * NPAR + seq_c
+        return par_a, par_b, c_par, rest[:NSEQ], rest[NSEQ:2 * NSEQ], rest[2 * NSEQ:]
 
-    def challenge(ev):
-        return (int.from_bytes(hashlib.sha3_256(ev).digest(), "little") % R_MOD).to_bytes(32, "little")
+    def challenge(ev, rnd):
+        return (int.from_bytes(hashlib.sha3_256(ev + bytes([rnd])).digest(), "little") % R_MOD).to_bytes(32, "little")
 
     res = {"workload": f"batched cubic sumcheck, {NPAR} par + {NSEQ} seq instances, tables of 2^{logn}, {logn} rounds, {round(ntab * n * 32 / 2**30, 2)} GiB in round 0"}
     finals = {}
-    for mode in ("separate", "fused"):
+    chal_used = None
+    for mode in ("stateful", "fused", "separate"):
         times = []; prof = {}
         reps = 2 if mode == "separate" else 3
         for rep in range(reps):
-            ts, As, Bs, Cs = fresh()
-            if mode == "fused" and rep == 0:                       # parity gate on round 0 (one par, one seq instance) against the oracle
-                ev0 = ctx.sc_eval_cubic_batched(As, Bs, Cs)
-                for inst in (0, NPAR):
-                    a, b, c_ = (ctx.table_download(t) for t in (As[inst], Bs[inst], Cs[inst]))
-                    if ev0[96 * inst:96 * inst + 96] != ol.sc_eval_cubic(a, b, c_):
-                        raise SystemExit(f"sumcheck block: round-0 sums of instance {inst} differ from the oracle")
+            gate = mode == "stateful" and rep == 0
+            ts, host = fresh(keep_host=gate)
+            pa, pb, pc, sa, sb_, sc_ = split(ts)
+            As, Bs, Cs = pa + sa, pb + sb_, [pc] * NPAR + sc_
             ctx.prof_enable(True); ctx.prof_reset()
             ctx.sync(); t0 = time.perf_counter()
-            ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
-            for rnd in range(logn):
-                r = challenge(ev)
-                if mode == "fused" and len(ts[0]) >= 4:
-                    ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
-                else:
-                    ctx.bind_top_many(ts, r)
-                    if len(ts[0]) >= 2:
-                        ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
-            ctx.sync(); dtm = time.perf_counter() - t0
+            if mode == "stateful":
+                st, ev = ctx.sumcheck_begin(pa, pb, pc, sa, sb_, sc_, coeffs)
+                evs, chs = [ev], []
+                for rnd in range(logn):
+                    chs.append(challenge(ev, rnd))
+                    ev = st.round(chs[-1]); evs.append(ev)
+                fin = st.finish()
+                ctx.sync(); dtm = time.perf_counter() - t0
+                st.free()
+                if gate:                                           # the whole sumcheck against the oracle's loop on the same tables
+                    hp = split(host)
+                    _, want_comb, want_fin = ol.sc_prove_cubic_batched(hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], coeffs, b"".join(chs), min(len(os.sched_getaffinity(0)), 16))
+                    for j in range(logn):
+                        if evs[j] != want_comb[j]:
+                            raise SystemExit(f"sumcheck block: combined sums of round {j} differ from the oracle")
+                    if fin != want_fin:
+                        raise SystemExit("sumcheck block: final claims differ from the oracle")
+                    del host, hp
+                finals[mode] = fin; chal_used = chs
+            else:
+                ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+                for rnd in range(logn):
+                    r = chal_used[rnd]                               # the same challenges: the three drivers must end in the same claims
+                    if mode == "fused" and len(ts[0]) >= 4:
+                        ev = ctx.sc_bind_eval_cubic_batched(As, Bs, Cs, r)
+                    else:
+                        ctx.bind_top_many(ts, r)
+                        if len(ts[0]) >= 2:
+                            ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
+                ctx.sync(); dtm = time.perf_counter() - t0
+                finals[mode] = [ctx.table_read0(t) for t in ts]
             prof = ctx.prof_get(); ctx.prof_enable(False)
-            finals[mode] = [ctx.table_read0(t) for t in ts]
             for t in ts:
                 t.free()
             if rep:
                 times.append(dtm)
         res[mode] = {"ms_per_sumcheck": round(1e3 * sum(times) / len(times), 3), "kernels_ms_total": {k: round(v[0], 3) for k, v in prof.items()},
                      "kernels_launches": {k: v[1] for k, v in prof.items()}}
-    if finals["separate"] != finals["fused"]:
-        raise SystemExit("sumcheck block: fused and separate rounds disagree on the final table values")
+    if not (finals["separate"] == finals["fused"] == finals["stateful"]):
+        raise SystemExit("sumcheck block: the three drivers disagree on the final table values")
     table_bytes = ntab * n * 32
+    par_bytes = (2 * NPAR) * n * 32
     # eval reads every live table once, a bind reads it once and writes half; live bytes halve per round (sum over rounds = 2 x round 0)
     alg_sep = 2 * table_bytes * (1 + 1 + 0.5)
     alg_first = table_bytes
     alg_fused_rounds = 2 * table_bytes * (1 + 0.5)
-    for mode, alg in (("separate", alg_sep), ("fused", alg_first + alg_fused_rounds)):
+    for mode, alg in (("separate", alg_sep), ("fused", alg_first + alg_fused_rounds), ("stateful", alg_first + alg_fused_rounds)):
         ms = res[mode]["ms_per_sumcheck"]
         res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
         res[mode]["GBps_end_to_end"] = round(alg / (ms * 1e-3) / 1e9, 1)
-    kf = res["fused"]["kernels_ms_total"]
-    # dominant kernel: the streaming fused round (tables of 2^16 entries and more) together with the out-of-place bind of the shared C
-    # table that belongs to it; the later rounds (single-launch kernel, launch-latency bound) are reported next to it
+    # the streaming rounds (tables of 2^16 entries and more): all three kernels that make up such a round
     npf = max(0, logn - 15)
-    stream_ms = kf.get("k_sc_bind_eval_cubic_stream", 0.0) + kf.get("k_bind_oop", 0.0)
-    small_ms = kf.get("k_sc_bind_eval_cubic", 0.0) + kf.get("k_bind_top", 0.0)
-    if stream_ms and npf:
-        alg_stream = table_bytes * 1.5 * sum(0.5 ** j for j in range(npf))          # round j reads its live tables once and writes half
+    geo = sum(0.5 ** j for j in range(npf))
+    ks = res["stateful"]["kernels_ms_total"]; kl = res["stateful"]["kernels_launches"]
+    comb_ms, comb_n = ks.get("k_sc_comb_bind_eval", 0.0), kl.get("k_sc_comb_bind_eval", 0)
+    stream_ms = comb_ms + ks.get("k_sc_bind_eval_cubic_stream", 0.0) + ks.get("k_bind_oop", 0.0)
+    small_ms = ks.get("k_sc_bind_eval_cubic", 0.0) + ks.get("k_bind_top", 0.0)
+    if stream_ms and npf and comb_n:
+        # the combined kernel runs on every round with >= 2^13 index pairs: comb_n launches, "par" tables + the bound shared C
+        geo_c = sum(0.5 ** j for j in range(comb_n))
+        alg_comb = (par_bytes * 1.5 + n * 32 * 0.5) * geo_c
+        ach_c = alg_comb / (comb_ms * 1e-3) / 1e9
+        alg_stream = table_bytes * 1.5 * geo + (alg_comb - (par_bytes * 1.5 + n * 32 * 0.5) * geo)     # + the combined kernel's launches below 2^16 entries
         ach = alg_stream / (stream_ms * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_bind_eval_pf<CUBIC> (+ k_bind_oop of the shared table)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": npf, "kernel_avg_ms": round(stream_ms / npf, 4),
-                           "algorithmic_bytes_per_launch": int(alg_stream / npf), "kernel_ms_streaming_rounds": round(stream_ms, 3),
-                           "note": "kernel-only, per launch averaged over the %d streaming rounds of one sumcheck (table bytes halve per round); 43 distinct tables read once, bound halves written once" % npf,
+        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_comb_bind_eval (the 12 'par' instances: bind + combined sums, one reduction per index)", "achieved": round(ach_c, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach_c / HBM_PEAK_GBS, 4), "traffic": None, "launches": comb_n, "kernel_avg_ms": round(comb_ms / comb_n, 4),
+                           "algorithmic_bytes_per_launch": int(alg_comb / comb_n), "kernel_ms_total": round(comb_ms, 3),
+                           "note": "kernel-only (HIP events on the context's stream), per launch averaged over its %d launches of one sumcheck (table bytes halve per round): 24 tables read once, bound halves written once, the bound shared C read once" % comb_n,
+                           "streaming_rounds_all_kernels": {"kernels": "k_sc_comb_bind_eval + k_sc_bind_eval_pf<CUBIC> (the 6 'seq' instances) + k_bind_oop (shared C)", "kernel_ms": round(stream_ms, 3),
+                                                            "algorithmic_bytes": int(alg_stream), "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+                                                            "note": "every kernel of the rounds on tables of 2^16 entries and more (43 tables read once, bound halves written once); the figure round 2 reported as its roofline"},
                            "all_fused_rounds": {"kernel_ms": round(stream_ms + small_ms, 3), "algorithmic_bytes": int(alg_fused_rounds),
                                                 "GBps": round(alg_fused_rounds / ((stream_ms + small_ms) * 1e-3) / 1e9, 1),
-                                                "note": "incl. the %d launch-latency-bound rounds on tables below 2^16 entries" % (logn - 1 - npf)}}
-        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_bind_eval_pf")
+                                                "note": "incl. the launch-latency-bound rounds on small tables"}}
+        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_comb_bind_eval")
         if st:
             res["roofline"]["traffic"] = int(st[0])
-            res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per streaming launch; not measured by this run)"
+            res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per launch; not measured by this run)"
     ke = res["separate"]["kernels_ms_total"]
     if ke.get("k_sc_eval_cubic") and ke.get("k_bind_top"):
         res["separate"]["eval_GBps"] = round(2 * table_bytes / (ke["k_sc_eval_cubic"] * 1e-3) / 1e9, 1)
         res["separate"]["bind_GBps"] = round(2 * table_bytes * 1.5 / (ke["k_bind_top"] * 1e-3) / 1e9, 1)
-    res["parity"] = "round-0 sums of one par and one seq instance bit-exact vs the CPU oracle; fused and separate paths agree on all 43 final values"
+    res["parity"] = "stateful driver: the combined sums of all %d rounds and the 43 final claims bit-exact vs the CPU oracle's prove_cubic_batched loop on the same tables; fused and separate drivers agree with it on all 43 final values" % logn
     return res
+
+
+def prove_stages_block(ctx, sbn, lookup_bytes):
+    """BASELINE config 5: the device-side stages of one keyless-shaped SNARK::prove (Hyrax mode), issued by COMPILED code through the
+    C ABI (spartan-bn254_amd/harness/prove_stages.cpp: the call sequence of the Rust shim in INTEGRATION.md), timed per stage under the
+    names of the reference's benchmark (examples/keyless_benchmark.rs:171-238).  Parity gate first: the same harness at 2^-14 of the
+    size with its trace on, replayed against the CPU oracle (tests/harness_model.py) — every commitment, round value and final claim."""
+    import harness_model
+    from spartan_bn254_amd import binding
+    t0 = time.perf_counter()
+    for stateful in (True, False):
+        _, digest, trace, rounds = binding.harness_prove(ctx, 8, 7, 6, stateful=stateful, seed=11, trace_cap=8 << 20)
+        got = harness_model.replay(trace, 8, 7, 6, seed=11)
+        if got["digest"] != digest:
+            raise SystemExit("prove_stages: the small harness run does not replay against the oracle")
+    gate_s = time.perf_counter() - t0
+    LO, LM, LC = 22, 21, 20
+    out = {}
+    for name, stateful in (("stateful_sumcheck", True), ("per_instance_sumcheck", False)):
+        # three proves back to back on one setup (generator sets, their lookup tables, address arrays: per-circuit); the fastest is reported
+        stages, digest, _, rounds = binding.harness_prove(ctx, LO, LM, LC, stateful=stateful, lookup_bytes_sat=16 << 30, lookup_bytes_eval=lookup_bytes, seed=11, passes=3)
+        tot = sum(stages[k] for k in binding.HARNESS_STAGES[:6])
+        out[name] = {"total_device_side_ms": round(tot, 2), "stage_ms": {k: round(stages[k], 3) for k in binding.HARNESS_STAGES[:6]},
+                     "detail_ms": {k[4:]: round(stages[k], 3) for k in binding.HARNESS_STAGES[6:]}, "rounds": rounds, "transcript_digest": digest.hex()[:16]}
+    if out["stateful_sumcheck"]["transcript_digest"] != out["per_instance_sumcheck"]["transcript_digest"]:
+        raise SystemExit("prove_stages: the two sumcheck drivers absorbed different values at full size")
+    st = out["stateful_sumcheck"]
+    names = {"r1cs_sat_proof": "R1CS sat proof", "eq_evals": "EqPolynomial evaluation", "derefs_computation": "Derefs computation", "derefs_commitment": "Derefs commitment",
+             "network_construction": "Network construction", "network_proof": "Network proof"}
+    pub = {"r1cs_sat_proof": 3.45, "eq_evals": 0.10, "derefs_computation": 0.14, "derefs_commitment": 166.2, "network_construction": 4.07, "network_proof": 34.5}
+    return {"workload": "keyless-shaped SNARK::prove (Hyrax): num_cons = num_vars = 2^20, 6 sparse polynomials of 2^22 ops over 2^21 memory cells (SURVEY App. C); synthetic tables, "
+                        "uniform Fr; SHA3 chain in place of the Merlin transcript; fastest of three proves on one setup (generator sets, window / lookup tables, address arrays: per-circuit setup, outside the timed stages)",
+            "driver": "compiled C++ caller of the C ABI (libsbn_prove_harness.so), one ABI call per sumcheck round",
+            "stages": [{"stage": names[k], "ms": st["stage_ms"][k], "reference_published_s_M2Max_1thread": pub[k]} for k in binding.HARNESS_STAGES[:6]],
+            "total_device_side_ms": st["total_device_side_ms"], "reference_published_total_prove_s": 208.8,
+            "detail_ms": st["detail_ms"], "rounds": st["rounds"], "per_instance_sumcheck_calls": out["per_instance_sumcheck"],
+            "not_included": "host-side Rust control flow: Instance evaluations (sparse, keyless_benchmark.rs:185-188), SpMV Az/Bz/Cz, the Sigma-protocol steps of the ZK sumchecks "
+                            "(3-5 point commitments per round), Merlin hashing — they stay in Rust; the published figures include them",
+            "parity": "the same harness at 2^-14 of the size, both sumcheck drivers: every absorbed value (commitments, %d+ round values, final claims, bullet L/R) replayed against the CPU oracle (%.1f s); "
+                      "at full size both drivers end in the same transcript digest" % (got["records_checked"], gate_s)}
 
 
 if __name__ == "__main__":

@@ -74,7 +74,8 @@ HARNESS_STAGES = ["r1cs_sat_proof", "eq_evals", "derefs_computation", "derefs_co
 
 class HarnessParams(C.Structure):
     _fields_ = [("log_ops", C.c_int32), ("log_mem", C.c_int32), ("log_cons", C.c_int32), ("stateful_sumcheck", C.c_int32),
-                ("lookup_bytes_sat", C.c_uint64), ("lookup_bytes_eval", C.c_uint64), ("seed", C.c_uint64), ("rounds_out", C.c_uint32 * 4)]
+                ("lookup_bytes_sat", C.c_uint64), ("lookup_bytes_eval", C.c_uint64), ("seed", C.c_uint64), ("rounds_out", C.c_uint32 * 4),
+                ("passes", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _HARNESS = None
@@ -92,9 +93,11 @@ def harness_lib():
     return _HARNESS
 
 
-def harness_prove(ctx, log_ops, log_mem, log_cons, stateful=True, lookup_bytes_sat=0, lookup_bytes_eval=0, seed=1, trace_cap=0):
-    """one keyless-shaped prove's device-side stages from compiled code -> (stage_ms dict, digest, trace bytes, rounds dict)"""
+def harness_prove(ctx, log_ops, log_mem, log_cons, stateful=True, lookup_bytes_sat=0, lookup_bytes_eval=0, seed=1, trace_cap=0, passes=1):
+    """a keyless-shaped prove's device-side stages from compiled code -> (stage_ms dict, digest, trace bytes, rounds dict); with passes > 1
+    the proves run back to back on one setup and the fastest pass's times are returned (the trace is the last pass's)"""
     prm = HarnessParams(log_ops, log_mem, log_cons, 1 if stateful else 0, lookup_bytes_sat, lookup_bytes_eval, seed)
+    prm.passes = passes
     ms = (C.c_double * 16)(); dig = (C.c_uint8 * 32)(); err = C.create_string_buffer(512)
     tr = (C.c_uint8 * trace_cap)() if trace_cap else None; tl = C.c_size_t(0)
     rc = harness_lib().sbn_harness_prove(ctx.h, C.byref(prm), ms, dig, tr, C.c_size_t(trace_cap), C.byref(tl), err, C.c_size_t(512))

@@ -106,6 +106,8 @@ struct sbn_harness_params {
   uint64_t lookup_bytes_sat, lookup_bytes_eval;   // sbn_bases_precompute budgets of the two generator sets (0: bucket method)
   uint64_t seed;
   uint32_t rounds_out[4];                  // out: sumcheck rounds (ops, mem), bullet rounds, layers
+  uint32_t passes;                         // >= 1: proves run back to back on ONE setup (generator sets, lookup tables, address arrays); the times of the fastest are returned
+  uint32_t reserved;
 };
 
 struct Harness {
@@ -269,6 +271,11 @@ struct Harness {
       d_addr[k] = upload_u32(a); d_rts[k] = upload_u32(ts);
     }
     for (int s = 0; s < 2; s++) { std::vector<uint32_t> ts(nmem); for (size_t i = 0; i < nmem; i++) ts[i] = (uint32_t)(splitmix(p->seed * 7919ull + ((uint64_t)(s + 8) << 40) + i) % 64); d_ats[s] = upload_u32(ts); }
+    double best_ms[ST_COUNT]; double best_total = -1;
+    const uint32_t passes = p->passes ? p->passes : 1;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+    memset(h, 0, 32); trace_len = 0; p_rounds_bullet = p_rounds_ops = p_rounds_mem = p_layers = 0;
+    for (int i = 0; i < ST_COUNT; i++) ms[i] = 0;
     sbn_table* z = synth_table(ncons, 1);
     {   // the first commit on a generator set builds its window table: setup
       std::vector<uint8_t> o(64 << wl); chk(sbn_commit_table(ctx, gens_w, z, nullptr, (size_t)1 << wl, (size_t)1 << wr, o.data(), nullptr), "warm commit");
@@ -369,6 +376,10 @@ struct Harness {
       sbn_table_free(ctx, comb_mem);
     }
     sbn_table_free(ctx, comb); sbn_table_free(ctx, mem_rx); sbn_table_free(ctx, mem_ry);
+    double total = 0; for (int i = 0; i <= ST_NETWORK_PROOF; i++) total += ms[i];
+    if (best_total < 0 || total < best_total) { best_total = total; memcpy(best_ms, ms, sizeof ms); }
+    }   // passes
+    memcpy(ms, best_ms, sizeof ms);
     for (void* d : d_addr) sbn_dev_free(ctx, d);
     for (void* d : d_rts) sbn_dev_free(ctx, d);
     for (void* d : d_ats) sbn_dev_free(ctx, d);
