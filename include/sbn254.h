@@ -244,6 +244,37 @@ int sbn_gather_merge(sbn_ctx* ctx, const sbn_table* const* mem, const void* cons
 int sbn_commit_table(sbn_ctx* ctx, const sbn_bases* b, const sbn_table* t, const uint8_t* blinds, size_t L, size_t R,
                      uint8_t* out_xy, uint8_t* out_inf);
 
+/* ---- device groups: ONE host process, several GPUs behind one call ----
+ * The reference parallelises inside one process (rayon over the rows of the Hyrax matrix, hyrax.rs:259-261; arkworks over the windows of
+ * an MSM), so its drop-in has one process too: a group owns one context per listed device (a device may be listed more than once) and
+ * runs every call with one host thread per device.  Nothing here needs a launcher or a collective library.
+ *   rows of ONE matrix: row i on device i mod N, no exchange (rows are independent);
+ *   ONE MSM: contiguous base-point ranges, the N 64-byte partial sums folded on the host with sbn_g1_sum (group.rs:199-262). */
+typedef struct sbn_group sbn_group;
+typedef struct sbn_group_bases sbn_group_bases;
+int sbn_group_create(const int* devices, size_t n, sbn_group** out);
+void sbn_group_destroy(sbn_group* g);
+size_t sbn_group_size(const sbn_group* g);
+sbn_ctx* sbn_group_ctx(sbn_group* g, size_t i);                 /* the i-th device's context (for the single-device calls above) */
+const char* sbn_group_last_error(const sbn_group* g);
+/* MultiCommitGens (commitments.rs:17-27) replicated on every device of the group */
+int sbn_group_bases_upload(sbn_group* g, const uint8_t* G_xy, size_t n, const uint8_t* h_xy, uint32_t flags, sbn_group_bases** out);
+int sbn_group_gens_new(sbn_group* g, size_t n, const uint8_t* label, size_t label_len, uint8_t* out_xy, sbn_group_bases** out);
+int sbn_group_bases_precompute(sbn_group* g, sbn_group_bases* gb, size_t max_bytes_per_device, int* window_bits);
+void sbn_group_bases_free(sbn_group* g, sbn_group_bases* gb);
+/* DensePolynomial::commit -> commit_inner (hyrax.rs:253-267) of ONE L x R matrix (host pointer) over the group; arguments as sbn_commit_rows */
+int sbn_group_commit_rows(sbn_group* g, const sbn_group_bases* gb, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R,
+                          uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
+/* GroupElement::msm_affine (group.rs:171-175) of ONE MSM over the group: device d takes the pairs [d n / N, (d+1) n / N) */
+int sbn_group_msm(sbn_group* g, const uint8_t* scalars, const uint8_t* points, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf);
+/* the same with resident points: cut once into the per-device ranges (no h), then only scalars travel */
+int sbn_group_bases_upload_ranges(sbn_group* g, const uint8_t* G_xy, size_t n, uint32_t flags, sbn_group_bases** out);
+int sbn_group_bases_synthetic_ranges(sbn_group* g, size_t n, const uint8_t s0[32], const uint8_t d[32], sbn_group_bases** out);   /* sbn_bases_synthetic, range by range */
+void sbn_group_range(const sbn_group_bases* gb, size_t device, size_t* lo, size_t* hi);
+int sbn_group_msm_bases(sbn_group* g, const sbn_group_bases* gb, const uint8_t* scalars, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf);
+/* scalars_dev[d]: device pointer ON device d to the (hi - lo) x 32 B of its range */
+int sbn_group_msm_bases_dev(sbn_group* g, const sbn_group_bases* gb, const void* const* scalars_dev, uint32_t flags, uint8_t out_xy[64], int* out_is_inf);
+
 /* ---- per-kernel timing (HIP events on the context's stream), for bench.py's roofline line ---- */
 int sbn_prof_enable(sbn_ctx* ctx, int on);
 int sbn_prof_reset(sbn_ctx* ctx);

@@ -5,6 +5,6 @@ Rust shim would.  It contains no arithmetic and no fallback: if
 gfx950 device is missing, loading / context creation raises.
 """
 from .binding import (  # noqa: F401
-    Context, Bases, Table, SbnError, lib, lib_path, build_library,
+    Context, Group, Bases, Table, SbnError, lib, lib_path, build_library,
     SBN_SCALARS_MONT, SBN_POINTS_MONT, g1_compress, g1_sum, unipoly_from_evals, unipoly_eval, factored_lens, EXPORTED_SYMBOLS,
 )

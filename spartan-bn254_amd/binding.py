@@ -16,6 +16,8 @@ EXPORTED_SYMBOLS = [
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
     "sbn_sumcheck_begin", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
+    "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
+    "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
     "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
@@ -60,8 +62,11 @@ def lib():
         L.sbn_table_len.restype = C.c_size_t
         L.sbn_bullet_len.restype = C.c_size_t
         L.sbn_sumcheck_len.restype = C.c_size_t
+        L.sbn_group_size.restype = C.c_size_t
+        L.sbn_group_ctx.restype = C.c_void_p
+        L.sbn_group_last_error.restype = C.c_char_p
         L.sbn_factored_lens.restype = None
-        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free", "sbn_bullet_free", "sbn_sumcheck_free"):
+        for name in ("sbn_ctx_destroy", "sbn_bases_free", "sbn_table_free", "sbn_bullet_free", "sbn_sumcheck_free", "sbn_group_destroy", "sbn_group_bases_free", "sbn_group_range"):
             getattr(L, name).restype = None
         _LIB = L
     return _LIB
@@ -225,7 +230,93 @@ class Table:
             self.h = None
 
 
+class GroupBases:
+    def __init__(self, group, handle):
+        self.group, self.h = group, handle
+
+    def range(self, device):
+        lo, hi = C.c_size_t(), C.c_size_t()
+        lib().sbn_group_range(self.h, C.c_size_t(device), C.byref(lo), C.byref(hi)); return lo.value, hi.value
+
+    def free(self):
+        if self.h:
+            lib().sbn_group_bases_free(self.group.h, self.h); self.h = None
+
+
+class Group:
+    """sbn_group_*: one process, several devices behind one call (a device may be listed more than once)"""
+
+    def __init__(self, devices):
+        self.h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = lib().sbn_group_create(arr, C.c_size_t(len(devices)), C.byref(self.h))
+        if rc:
+            raise SbnError(f"sbn_group_create failed rc={rc}")
+
+    def close(self):
+        if self.h:
+            lib().sbn_group_destroy(self.h); self.h = None
+
+    def __len__(self):
+        return lib().sbn_group_size(self.h)
+
+    def _chk(self, rc, what):
+        if rc:
+            raise SbnError(f"{what}: rc={rc}: {lib().sbn_group_last_error(self.h).decode()}")
+
+    def ctx(self, i):
+        """the i-th device's context as a (non-owning) Context"""
+        c = Context.__new__(Context); c.h = C.c_void_p(lib().sbn_group_ctx(self.h, C.c_size_t(i))); c.owned = False
+        return c
+
+    def bases_upload(self, G_xy, h_xy=None, flags=0):
+        o = C.c_void_p()
+        self._chk(lib().sbn_group_bases_upload(self.h, _ptr(G_xy), C.c_size_t(len(G_xy) // 64), _ptr(h_xy), C.c_uint32(flags), C.byref(o)), "sbn_group_bases_upload")
+        return GroupBases(self, o)
+
+    def gens_new(self, n, label, want_points=True):
+        o = C.c_void_p(); out = (C.c_uint8 * (64 * (n + 1)))() if want_points else None
+        self._chk(lib().sbn_group_gens_new(self.h, C.c_size_t(n), _ptr(label), C.c_size_t(len(label)), out, C.byref(o)), "sbn_group_gens_new")
+        return GroupBases(self, o), (bytes(out) if want_points else None)
+
+    def bases_precompute(self, gb, max_bytes_per_device):
+        cw = C.c_int(0)
+        self._chk(lib().sbn_group_bases_precompute(self.h, gb.h, C.c_size_t(max_bytes_per_device), C.byref(cw)), "sbn_group_bases_precompute"); return cw.value
+
+    def commit_rows(self, gb, Z, blinds, L, R, flags=0):
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_group_commit_rows(self.h, gb.h, _ptr(Z), _ptr(blinds), C.c_size_t(L), C.c_size_t(R), C.c_uint32(flags), out, inf), "sbn_group_commit_rows")
+        return bytes(out), bytes(inf)
+
+    def msm(self, scalars, points, flags=0):
+        out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_group_msm(self.h, _ptr(scalars), _ptr(points), C.c_size_t(len(scalars) // 32), C.c_uint32(flags), out, C.byref(inf)), "sbn_group_msm")
+        return bytes(out), bool(inf.value)
+
+    def bases_upload_ranges(self, G_xy, flags=0):
+        o = C.c_void_p()
+        self._chk(lib().sbn_group_bases_upload_ranges(self.h, _ptr(G_xy), C.c_size_t(len(G_xy) // 64), C.c_uint32(flags), C.byref(o)), "sbn_group_bases_upload_ranges")
+        return GroupBases(self, o)
+
+    def bases_synthetic_ranges(self, n, s0, d):
+        o = C.c_void_p()
+        self._chk(lib().sbn_group_bases_synthetic_ranges(self.h, C.c_size_t(n), _ptr(s0), _ptr(d), C.byref(o)), "sbn_group_bases_synthetic_ranges")
+        return GroupBases(self, o)
+
+    def msm_bases(self, gb, scalars, flags=0):
+        out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_group_msm_bases(self.h, gb.h, _ptr(scalars), C.c_size_t(len(scalars) // 32), C.c_uint32(flags), out, C.byref(inf)), "sbn_group_msm_bases")
+        return bytes(out), bool(inf.value)
+
+    def msm_bases_dev(self, gb, dev_ptrs, flags=0):
+        arr = (C.c_void_p * len(dev_ptrs))(*dev_ptrs); out = (C.c_uint8 * 64)(); inf = C.c_int()
+        self._chk(lib().sbn_group_msm_bases_dev(self.h, gb.h, arr, C.c_uint32(flags), out, C.byref(inf)), "sbn_group_msm_bases_dev")
+        return bytes(out), bool(inf.value)
+
+
 class Context:
+    owned = True
+
     def __init__(self, device=0):
         self.h = C.c_void_p()
         rc = lib().sbn_ctx_create(device, C.byref(self.h))
@@ -233,9 +324,9 @@ class Context:
             raise SbnError(f"sbn_ctx_create failed rc={rc} (no gfx950 device? there is no CPU fallback)")
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             lib().sbn_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __enter__(self):
         return self

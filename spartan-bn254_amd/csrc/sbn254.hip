@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -37,6 +38,7 @@ using namespace sbn;
 #include "abi_tables.inc"
 #include "abi_sumcheck.inc"
 #include "abi_bullet.inc"
+#include "abi_group.inc"
 
 extern "C" {
 
