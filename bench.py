@@ -162,6 +162,8 @@ def main():
                     "(the padded tail of every derefs matrix repeats mem[0], sparse_mlpoly_full.rs:89-101; ~0.43 at keyless size)")
     ap.add_argument("--precompute-gb", type=float, default=200.0, help="hyrax: HBM budget (GiB) of the fixed-base lookup table of the generator set "
                     "(sbn_bases_precompute; built once before the timed region like any commitment-key setup); 0 = bucket method only")
+    ap.add_argument("--group-devices", default="", help="comma list of device indices (repeats allowed): adds a `group` block — ONE Hyrax matrix and ONE 2^26 MSM over "
+                    "those devices from THIS process through the C ABI's device groups (sbn_group_*: host threads per device, no launcher, no collective); needs --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -466,6 +468,44 @@ def main():
                 if comb_c:
                     r["lookup_table"] = {"window_bits": comb_c, "build_s": round(tpre, 2)}
                 res[name] = r
+            if world == 1:
+                # SURVEY 8d config 3's other variants, on the handle as the loop left it (lookup table attached when it fitted), each
+                # parity-gated on sampled rows before it is timed
+                method = "lookup" if (res.get("lookup") or {}).get("lookup_table") else "bucket"
+                var = {}
+
+                def timed_variant(handle, Zt, Lt, gx_bytes, hx_bytes, rows_chk):
+                    o, _ = ctx.commit_rows_dev(handle, Zt.data_ptr(), 0, Lt, Rc)
+                    Zt2 = Zt.view(Lt, Rc * 32)
+                    for i in rows_chk:
+                        if o[64 * i:64 * i + 64] != ol.commit(Zt2[i].cpu().numpy().tobytes(), bytes(32), gx_bytes, hx_bytes):
+                            raise SystemExit(f"hyrax variant: row {i} differs from the oracle")
+                    ks = 3
+                    vdt = timer.run(lambda: ctx.commit_rows_dev(handle, Zt.data_ptr(), 0, Lt, Rc), ks)
+                    return {"ms_per_step": round(vdt / ks * 1e3, 4), "pairs_per_s": round(Lt * Rc * ks / vdt, 1), "window_bits": ctx.prof_last_job()["c"]}
+
+                # (1) the padded suffix of every derefs matrix repeats one constant (sparse_mlpoly_full.rs:89-101; ~43 % of the non-zero rows at keyless size)
+                Zc = Z.clone(); Zv = Zc.view(L, Rc * 32); blk = max(1, L // 8)
+                for b0 in range(0, 3 * L // 4, blk):
+                    k0 = b0 + int(blk * 0.57)
+                    Zv[k0:b0 + blk] = Zv[k0:k0 + 1, :32].repeat(1, Rc)
+                torch.cuda.synchronize()
+                var["const_tail_0.43"] = dict(timed_variant(hb, Zc, L, gxy[:64 * Rc], gxy[64 * Rc:], (0, int(blk * 0.57), blk - 1, 3 * L // 4 - 1, L - 1)), method=method,
+                                              note="the last 43 % of the rows of every 512-row block hold one repeated constant (the mem[0] lookups of padded ops)")
+                del Zc, Zv
+                # (2) BASELINE.json's "~2^24 points": 2048 x 8192
+                L2 = L // 2
+                Z2 = Z[:32 * L2 * Rc].clone(); Z2.view(L2, Rc * 32)[(3 * L2 // 4):] = 0; torch.cuda.synchronize()
+                var[f"{L2}x{Rc}"] = dict(timed_variant(hb, Z2, L2, gxy[:64 * Rc], gxy[64 * Rc:], (0, L2 // 2, 3 * L2 // 4 - 1, L2 - 1)), method=method, note="2^24 (scalar, base) pairs, rows >= 3L/4 zero")
+                del Z2
+                # (3) 8192 DISTINCT bases (the reference's derivation makes 66 % of its generators equal: nothing to merge here)
+                db = ctx.bases_synthetic(Rc, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+                dxy = ctx.bases_download(db, 0, Rc)
+                var["distinct_bases"] = dict(timed_variant(db, Z, L, dxy, G_XY, (0, L // 2 + 1, 3 * L // 4 - 1, L - 1)), method="bucket", note=f"{Rc} distinct points, no h, same {L}x{Rc} matrix")
+                db.free()
+                for v in var.values():
+                    v["parity"] = "sampled rows bit-exact vs the CPU oracle"
+                res["variants"] = var
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 cores = min(len(os.sched_getaffinity(0)), 16)
                 rows = min(L, 2 * cores)
@@ -539,6 +579,13 @@ def main():
             line_extra["prove_stages"] = prove_stages_block(ctx, sbn, int(args.precompute_gb * (1 << 30)))
         except sbn.SbnError as e:
             line_extra["prove_stages"] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
+    if args.group_devices and world == 1:
+        try:
+            line_extra["group"] = group_block(sbn, ol, torch, [int(x) for x in args.group_devices.split(",")], args.rows, args.cols, args.strong_log_n)
+        except sbn.SbnError as e:
+            line_extra["group"] = {"error": str(e)}
         torch.cuda.empty_cache()
 
     if rank == 0:
@@ -685,6 +732,58 @@ def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
         res["separate"]["eval_GBps"] = round(2 * table_bytes / (ke["k_sc_eval_cubic"] * 1e-3) / 1e9, 1)
         res["separate"]["bind_GBps"] = round(2 * table_bytes * 1.5 / (ke["k_bind_top"] * 1e-3) / 1e9, 1)
     res["parity"] = "stateful driver: the combined sums of all %d rounds and the 43 final claims bit-exact vs the CPU oracle's prove_cubic_batched loop on the same tables; fused and separate drivers agree with it on all 43 final values" % logn
+    return res
+
+
+def group_block(sbn, ol, torch, devices, L, Rc, log_n):
+    """SURVEY 8e from ONE process: the C ABI's device groups (sbn_group_*, csrc/abi_group.inc).  ONE L x Rc matrix committed by
+    interleaved rows (host matrix: the figure includes PCIe) and ONE 2^log_n MSM by base-point ranges with resident points and
+    device-resident scalar slices; both parity-gated (sampled rows vs the oracle; the discrete-log identity)."""
+    g = sbn.Group(devices)
+    N = len(devices)
+    res = {"devices": devices, "driver": "one process, one host thread per device inside the library; no collective"}
+    try:
+        gb, gxy = g.gens_new(Rc, b"gens_r1cs_eval")
+        c0 = g.ctx(0)
+        Z = torch.empty(32 * L * Rc, dtype=torch.uint8, device=f"cuda:{devices[0]}")
+        c0.scalars_synthetic(SEED, 1 << 40, L * Rc, Z.data_ptr())
+        Z.view(L, Rc * 32)[(3 * L // 4):] = 0
+        torch.cuda.synchronize()
+        Zh = Z.cpu().numpy(); del Z
+        out, _ = g.commit_rows(gb, Zh, None, L, Rc)
+        for i in (0, 1, N, L // 2 + 1, 3 * L // 4 - 1, L - 1):
+            row = Zh[32 * Rc * i:32 * Rc * (i + 1)].tobytes()
+            if out[64 * i:64 * i + 64] != ol.commit(row, bytes(32), gxy[:64 * Rc], gxy[64 * Rc:]):
+                raise SystemExit(f"group: row {i} differs from the oracle")
+        t0 = time.perf_counter(); reps = 3
+        for _ in range(reps):
+            g.commit_rows(gb, Zh, None, L, Rc)
+        dt = (time.perf_counter() - t0) / reps
+        res["hyrax_rows"] = {"shape": f"{L}x{Rc}", "ms_per_commit_incl_pcie": round(dt * 1e3, 2), "pairs_per_s": round(L * Rc / dt, 1), "sharding": f"row i on device i mod {N}, no reduction",
+                             "parity": "6 sampled rows bit-exact vs the CPU oracle", "note": "host-pointer entry point: the 1 GiB matrix crosses PCIe inside the timed call"}
+        gb.free(); del Zh
+        n = 1 << log_n
+        gr = g.bases_synthetic_ranges(n, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+        slices, want_sum = [], 0
+        for d in range(N):
+            lo, hi = gr.range(d)
+            t = torch.empty(32 * (hi - lo), dtype=torch.uint8, device=f"cuda:{devices[d]}")
+            g.ctx(d).scalars_synthetic(SEED, lo, hi - lo, t.data_ptr())
+            torch.cuda.synchronize(devices[d])
+            want_sum = (want_sum + int.from_bytes(dlog_expect(t, lo, hi - lo), "little")) % R_MOD
+            slices.append(t)
+        got, inf = g.msm_bases_dev(gr, [t.data_ptr() for t in slices])
+        if got != ol.g1_mul(G_XY, want_sum.to_bytes(32, "little")):
+            raise SystemExit("group: the folded MSM differs from the discrete-log identity")
+        t0 = time.perf_counter(); reps = 3
+        for _ in range(reps):
+            g.msm_bases_dev(gr, [t.data_ptr() for t in slices])
+        dt = (time.perf_counter() - t0) / reps
+        res["msm"] = {"total_points": n, "ms_per_msm": round(dt * 1e3, 3), "points_per_s": round(n / dt, 1), "sharding": f"{N} contiguous base-point ranges, {N} x 64 B folded on the host (sbn_g1_sum)",
+                      "parity": "bit-exact vs the discrete-log identity"}
+        gr.free()
+    finally:
+        g.close()
     return res
 
 

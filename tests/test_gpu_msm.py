@@ -511,7 +511,7 @@ def test_large_msm_dlog_identity(ctx, ol, pr, logn):
         b.free()
 
 
-def test_hyrax_derefs_shape_properties(ctx, ol, pr):
+def test_hyrax_derefs_shape_properties(ctx, ol, pr, sbn):
     """BASELINE config 3: the derefs commitment shape 4096 x 8192 over the reference's generator set, rows
     3072.. zero (hyrax.rs:245).  Checked on sampled rows against single-row commits of the oracle + structure."""
     import torch
@@ -533,8 +533,15 @@ def test_hyrax_derefs_shape_properties(ctx, ol, pr):
         o2, _ = ctx.commit_rows_dev(bases, Z.data_ptr() + 32 * R * 1000, 0, 2, R)
         assert o2 == out[64 * 1000:64 * 1002]
         # fixed-base lookup table in HBM (sbn_bases_precompute): a different algorithm (no buckets), the same 4096 points
-        cw = ctx.bases_precompute(bases, 100 << 30)
-        assert 13 <= cw <= 16
+        # the table bench.py and the prove-stages harness use: c = 17, 177 GB for the 2814 unique points of this set; when the box cannot
+        # give that much HBM right now, the c = 16 table (94 GB) is what gets tested
+        try:
+            cw = ctx.bases_precompute(bases, 200 << 30)
+        except sbn.SbnError as e:
+            print(f"[test] 200 GiB lookup table not available ({e}); falling back to a 100 GiB budget")
+            cw = ctx.bases_precompute(bases, 100 << 30)
+        print(f"[test] lookup table window bits: {cw}")
+        assert 13 <= cw <= 17
         out3, infs3 = ctx.commit_rows_dev(bases, Z.data_ptr(), 0, L, R)
         assert out3 == out and infs3 == infs
         o4, _ = ctx.commit_rows_dev(bases, Z.data_ptr() + 32 * R * 1000, 0, 2, R)       # few rows: several blocks per row
