@@ -81,7 +81,9 @@ __device__ __forceinline__ void sc_flag_store(uint32_t* flag, uint32_t seq) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox
+constexpr int SC_MBOX_FLAGS = SC_PACK_MAX * 24;      // word offset of the flags inside the mailbox (SC_PACK_MAX round flags + 1 for the final claims)
+constexpr int SC_MBOX_FINALS = SC_MBOX_FLAGS + SC_PACK_MAX + 8;      // word offset of the final claims of a stateful sumcheck (up to 3 * SC_PACK_MAX + 1 tables x 8 words)
+constexpr int SC_MBOX_WORDS = SC_MBOX_FINALS + (3 * SC_PACK_MAX + 8) * 8;
 // The block's three running sums -> partial[(inst * gridDim.x + blockIdx.x) * 3 + q] (memory format, Montgomery domain).
 // mbox != nullptr with ONE block per instance (the tables of the last ~8 rounds): the block's sums are the round's values, so
 // they go straight to the host mailbox as canonical integers and the flag follows — no partial sums, no ticket, no device fence.
