@@ -252,6 +252,9 @@ template <class M> __device__ __forceinline__ void cols_mac(Cols& s, const Fe<M>
     for (int j = 0; j < NL; j++) s.c[i + j] += (uint64_t)a.v[i] * (uint64_t)b.v[j];
   }
 }
+// s += a (x) b with ONE lazy operand: a normalised (limbs below 2^29), b non-negative with limbs below 2^30.6 (a biased difference,
+// fe_subb / fe_negb).  Capacity: two such products before the reduction (2 * 9 * 2^59.6 + 9 * 2^58 < 2^64).
+template <class M> __device__ __forceinline__ void cols_mac_lazy(Cols& s, const Fe<M>& a, const Fe<M>& b) { cols_mac<M>(s, a, b); }
 // carries moved up (value unchanged): columns 0..15 below 2^29 afterwards, the top column takes what is left
 __device__ __forceinline__ void cols_carry(Cols& s) {
 #pragma unroll

@@ -96,8 +96,12 @@ __device__ __forceinline__ void xyzz_madd(XYZZ& acc, const Affine& q_in, bool ne
   }
   const Fq PP = fe_squ(P), PPP = fe_mulu(P, PP), Q = fe_mulu(acc.X, PP);
   const Fq X3 = fe_normu(fe_subb<FqP, 4, 3>(fe_squ(R), fe_add_lazy(fe_add_lazy(PPP, Q), Q)));        // R^2 - PPP - 2Q + 4p in (0.4p, 5.2p)
-  const Fq Y3 = fe_normu(fe_subb<FqP, 2, 1>(fe_mulu(R, fe_subb<FqP, 6, 1>(Q, X3)), fe_mulu(acc.Y, PPP)));   // in (0.8p, 3.2p)
-  acc.X = X3; acc.Y = Y3; acc.ZZ = fe_mulu(acc.ZZ, PP); acc.ZZZ = fe_mulu(acc.ZZZ, PPP);
+  // Y3 = R (Q - X3) - Y PPP as ONE sum of two products with ONE Montgomery reduction (fp.cuh: Cols): R (Q - X3 + 6p) + (4p - Y) PPP.
+  // Limb products: 2^29 x 2^30.6 and 2^30 x 2^29, nine per column each: 1.3e19 + the reduction's 2.6e18 < 2^64.  Value: at most
+  // (5.2 * 7.2 + 4 * 1.2) p^2 / 2^261 + p < 1.3 p, normalised by the reduction itself (no carry pass, no second reduction).
+  Cols cy; cols_zero(cy);
+  cols_mac_lazy<FqP>(cy, R, fe_subb<FqP, 6, 1>(Q, X3)); cols_mac_lazy<FqP>(cy, PPP, fe_negb<FqP, 4>(acc.Y));
+  acc.X = X3; acc.Y = cols_reduce<FqP>(cy); acc.ZZ = fe_mulu(acc.ZZ, PP); acc.ZZZ = fe_mulu(acc.ZZZ, PPP);
 }
 
 // a + b, both XYZZ (normalised, non-negative, ranges as above).  12M + 2S on the common path.  The inlined form is for the
@@ -114,7 +118,9 @@ __device__ __forceinline__ XYZZ xyzz_add_inl(const XYZZ& a, const XYZZ& b) {
   const Fq PP = fe_squ(P), PPP = fe_mulu(P, PP), Q = fe_mulu(U1, PP);
   XYZZ r;
   r.X = fe_normu(fe_subb<FqP, 4, 3>(fe_squ(R), fe_add_lazy(fe_add_lazy(PPP, Q), Q)));
-  r.Y = fe_normu(fe_subb<FqP, 2, 1>(fe_mulu(R, fe_subb<FqP, 6, 1>(Q, r.X)), fe_mulu(S1, PPP)));
+  Cols cy; cols_zero(cy);                                                            // R (Q - X3 + 6p) + (2p - S1) PPP, one reduction (see xyzz_madd); S1 < 1.2p
+  cols_mac_lazy<FqP>(cy, R, fe_subb<FqP, 6, 1>(Q, r.X)); cols_mac_lazy<FqP>(cy, PPP, fe_negb<FqP, 2>(S1));
+  r.Y = cols_reduce<FqP>(cy);
   r.ZZ = fe_mulu(fe_mulu(a.ZZ, b.ZZ), PP);
   r.ZZZ = fe_mulu(fe_mulu(a.ZZZ, b.ZZZ), PPP);
   return r;
