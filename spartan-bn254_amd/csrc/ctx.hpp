@@ -30,9 +30,6 @@ struct sbn_ctx {
   uint32_t* d_bad = nullptr;                 // device word: scalars >= r met by the kernels that read the caller's input (input_check_*)
   uint32_t* h_bad = nullptr;                 // its pinned host copy
   uint32_t* mbox = nullptr; uint32_t mbox_seq = 0;   // coherent pinned mailbox of the single-launch sumcheck rounds (results + per-instance flags)
-  // the persistent tail kernel of a stateful sumcheck (k_sc_tail): its own mailbox and its own stream (it stays resident between the
-  // caller's round calls; anything else the caller enqueues on this context must not queue up behind it); one tail at a time
-  uint32_t* tail_mbox = nullptr; uint32_t tail_seq = 0; hipStream_t tail_stream = nullptr; hipEvent_t tail_evt = nullptr; bool tail_busy = false; bool tail_ok = false;
   std::vector<std::pair<void*, size_t>> pool; size_t pool_bytes = 0;   // cached table buffers (see pool_get)
   uint64_t last_job[4] = {0, 0, 0, 0};      // window bits, windows, (digit, point) slots, buckets of the most recent bucket job
   // profiling

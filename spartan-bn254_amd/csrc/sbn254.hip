@@ -18,7 +18,6 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
-#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>

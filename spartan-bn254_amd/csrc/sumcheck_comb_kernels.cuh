@@ -177,126 +177,4 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_eval(const ScCombGroup* __re
   sc_last_block_fold_at(partial, tickets, out, 3, seq, slot0 + blockIdx.y);
 }
 
-
-// ---- the tail of a sumcheck: ALL remaining rounds in ONE launch ------------------------------------------------------------------
-// From tables of SC_TAIL_MAX_LEN entries down a round is a host round trip around a few microseconds of arithmetic: as separate
-// launches each costs ~10 us of kernel (launch, fold, flag) + ~16 us of gap (measured: 352 such rounds per keyless-shaped prove).
-// Here one block per instance copies its three tables into LDS once and then loops: bind to r_j in LDS, sum the next round, publish
-// the triple to the host mailbox, poll the mailbox for r_{j+1}.  No launch, no global-memory round trip, no cross-block hand-over per
-// round (the "par" instances each keep their own copy of the shared C: binding it twelve times costs nothing at this size).
-// Host <-> kernel protocol (coherent pinned memory, tail mailbox of the context):
-//   results   tm[slot * 24 ..]  three canonical scalars per instance, then  tm[TAIL_FLAGS + slot] = seq   (sc_flag_store: drained + released)
-//   challenge tm[TAIL_CHAL + 2 ..] = r in the tables' Montgomery form, then tm[TAIL_CHAL] = seq            (host: release store)
-//   abort     tm[TAIL_CHAL + 1] != 0: every block leaves at its next poll (the state was freed, or an error on the host side)
-// Every wait is bounded: a block that sees no challenge for SC_TAIL_TIMEOUT_TICKS of the 100 MHz real-time counter raises
-// tm[TAIL_CHAL + 10] and leaves — the grid always drains, whatever the host does.
-constexpr int SC_TAIL_MAX_LEN = 1024;                  // 3 tables x 1024 x 32 B = 96 KiB of LDS
-constexpr int TAIL_FLAGS = SC_PACK_MAX * 24;           // word offsets inside the tail mailbox
-constexpr int TAIL_FINALS = TAIL_FLAGS + SC_PACK_MAX + 8;      // per instance A[0], B[0], C[0] (canonical), then TAIL_FLAGS + SC_PACK_MAX = their flag
-constexpr int TAIL_CHAL = TAIL_FINALS + SC_PACK_MAX * 24;      // seq, abort, r[8], timed_out
-constexpr int TAIL_WORDS = TAIL_CHAL + 16;
-constexpr unsigned long long SC_TAIL_TIMEOUT_TICKS = 1000000000ull;   // 10 s at 100 MHz
-struct ScTailPack { const uint32_t* a[SC_PACK_MAX]; const uint32_t* b[SC_PACK_MAX]; const uint32_t* c[SC_PACK_MAX]; ScScalar scale[SC_PACK_MAX]; uint32_t has_scale[SC_PACK_MAX]; };
-
-__device__ __forceinline__ Fr fr_lds_get(const uint32_t* s, size_t i) {       // 8 words of element i (LDS, two 16-byte reads)
-  const uint4* q = reinterpret_cast<const uint4*>(s + 8 * i);
-  const uint4 lo = q[0], hi = q[1];
-  const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  return fe_unpack<FrP>(w);
-}
-__device__ __forceinline__ void fr_lds_put(uint32_t* s, size_t i, const Fr& a) {
-  uint32_t w[8]; fe_pack<FrP>(a, w);
-  uint4* q = reinterpret_cast<uint4*>(s + 8 * i);
-  q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-
-// eval_first != 0: the tables are fresh (round 0): publish their sums before the first challenge; otherwise r0 is the challenge of the
-// round that hands over (its sums were delivered by the launch before).  seq0: the sequence number of the first publication.
-__global__ void __launch_bounds__(512) k_sc_tail(ScTailPack pack, uint32_t len, ScScalar r0_mont, uint32_t eval_first, uint32_t* __restrict__ tm, uint32_t seq0) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_tab[];      // [3][len][8]
-  __shared__ uint32_t sm[8][3][NL];
-  __shared__ uint32_t s_ctl[12];                        // challenge words + go / abort
-  const int inst = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t* src[3] = {nullptr, nullptr, nullptr}; ScScalar sc; uint32_t has_scale = 0;
-#pragma unroll
-  for (int i = 0; i < SC_PACK_MAX; i++) if (i == inst) { src[0] = pack.a[i]; src[1] = pack.b[i]; src[2] = pack.c[i]; sc = pack.scale[i]; has_scale = pack.has_scale[i]; }
-  uint32_t* T[3] = {s_tab, s_tab + 8 * (size_t)len, s_tab + 16 * (size_t)len};
-  {
-    const Fr scale = fr_from_words(sc);
-    for (int t = 0; t < 3; t++)
-      for (size_t i = tid; i < len; i += blockDim.x) {
-        Fr x = fe_gload<FrP>(src[t] + 8 * i);
-        if (t == 0 && has_scale) x = fe_mulu(scale, x);                       // c_i folded into A as the table comes in
-        fr_lds_put(T[t], i, x);
-      }
-  }
-  __syncthreads();
-  Fr r = fr_from_words(r0_mont);
-  uint32_t seq = seq0;
-  bool need_bind = eval_first == 0;
-  for (;;) {
-    if (need_bind) {
-      const size_t half = len / 2;
-      for (size_t i = tid; i < half; i += blockDim.x)
-#pragma unroll 1
-        for (int t = 0; t < 3; t++) fr_lds_put(T[t], i, sc_bind1(fr_lds_get(T[t], i), fr_lds_get(T[t], i + half), r));     // in place: index i < half only
-      len = (uint32_t)half;
-      __syncthreads();
-    }
-    need_bind = true;
-    if (len == 1) break;
-    // the sums of this round (sumcheck.rs:201-235 for one instance)
-    const size_t h = len / 2;
-    Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
-    for (size_t i = tid; i < h; i += blockDim.x) {
-      const Fr al = fr_lds_get(T[0], i), ah = fr_lds_get(T[0], i + h), bl = fr_lds_get(T[1], i), bh = fr_lds_get(T[1], i + h), cl = fr_lds_get(T[2], i), ch = fr_lds_get(T[2], i + h);
-      const ScPts pa = sc_points_u(al, ah), pb = sc_points_u(bl, bh), pc = sc_points_u(cl, ch);
-      e0 = fe_add(e0, fe_mulu(fe_mulu(al, bl), cl)); e2 = fe_add(e2, fe_mulu(fe_mulu(pa.v2, pb.v2), pc.v2)); e3 = fe_add(e3, fe_mulu(fe_mulu(pa.v3, pb.v3), pc.v3));
-    }
-    e0 = wave_sum_fr(fe_reduce(e0)); e2 = wave_sum_fr(fe_reduce(e2)); e3 = wave_sum_fr(fe_reduce(e3));
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < NL; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
-    }
-    __syncthreads();
-    if (tid < 3) {
-      Fr s = fe_zero<FrP>();
-      for (int w = 0; w < (int)(blockDim.x >> 6); w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][tid][k]; s = fe_add(s, x); }
-      fe_store_packed<FrP>(tm + 8 * ((size_t)inst * 3 + tid), fe_from_mont(s));
-    }
-    sc_drain_stores();
-    __syncthreads();
-    if (tid == 0) {
-      sc_flag_store(tm + TAIL_FLAGS + inst, seq);
-      // wait for the next challenge (bounded)
-      seq++;
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      uint32_t go = 0;
-      for (;;) {
-        if (__hip_atomic_load(tm + TAIL_CHAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) { go = 1; break; }
-        if (__hip_atomic_load(tm + TAIL_CHAL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) break;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > SC_TAIL_TIMEOUT_TICKS) { __hip_atomic_store(tm + TAIL_CHAL + 10, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        __builtin_amdgcn_s_sleep(8);
-      }
-      if (go) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        for (int k = 0; k < 8; k++) s_ctl[k] = __hip_atomic_load(tm + TAIL_CHAL + 2 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      s_ctl[8] = go;
-    }
-    __syncthreads();
-    if (!s_ctl[8]) return;                                 // abort or time-out: every thread of the block leaves here
-    uint32_t w[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) w[k] = s_ctl[k];
-    r = fe_unpack<FrP>(w);
-    __syncthreads();                                       // s_ctl is rewritten in the next round
-  }
-  // final claims: A[0], B[0], C[0] of this instance (sumcheck.rs:302-318)
-  if (tid < 3) fe_store_packed<FrP>(tm + TAIL_FINALS + 8 * ((size_t)inst * 3 + tid), fe_from_mont(fr_lds_get(T[tid], 0)));
-  sc_drain_stores();
-  __syncthreads();
-  if (tid == 0) sc_flag_store(tm + TAIL_FLAGS + inst, seq);
-}
-
 }  // namespace sbn
