@@ -44,7 +44,7 @@ def kernels():
         ins = line.split("//")[0].strip()
         if ins and re.match(r"^[a-z]", ins):
             out[cur].append(ins)
-    return {k: v for k, v in out.items() if re.search(r"k_sc_(eval|bind_eval)", k)}
+    return {k: v for k, v in out.items() if re.search(r"k_sc_(eval|bind_eval|comb_eval|comb_bind_eval|finals)", k)}
 
 
 def is_vm_store(ins):
@@ -88,7 +88,8 @@ def check_signal(name, code, idx, what):
 
 def test_kernels_found(kernels):
     names = " ".join(kernels)
-    for frag in ("k_sc_evalILi0", "k_sc_evalILi1", "k_sc_evalILi2", "k_sc_bind_eval_pfILi0", "k_sc_bind_eval_tinyILi0", "k_sc_bind_evalILi0ELi2"):
+    for frag in ("k_sc_evalILi0", "k_sc_evalILi1", "k_sc_evalILi2", "k_sc_bind_eval_pfILi0", "k_sc_bind_eval_tinyILi0", "k_sc_bind_evalILi0ELi2", "k_sc_comb_eval", "k_sc_comb_bind_evalILb0", "k_sc_comb_bind_evalILb1",
+                 "k_sc_finals"):
         assert frag in names, f"{frag} missing from the code object"
 
 
@@ -103,7 +104,7 @@ def test_ticket_follows_drained_stores(kernels):
                 lo = max(0, i - 400)
                 wt = [k for k in range(lo, i) if code[k].startswith("global_store_dword ") and "sc0 sc1" in code[k] and not is_flag_store(code, k)]
                 assert len(wt) >= 8, f"{name}: the block's partial sums are not written through (sc0 sc1 dword stores) ahead of the ticket"
-    assert seen >= 12, f"only {seen} ticket adds found"           # 3 eval + 3 streaming + 9 plain fused kernels
+    assert seen >= 15, f"only {seen} ticket adds found"           # 3 eval + 3 streaming + 9 plain fused + 3 combined kernels
 
 
 def test_partial_sums_read_past_l1(kernels):
@@ -134,4 +135,4 @@ def test_mailbox_flag_follows_drained_results(kernels):
             assert waited, f"{name}: the flag store may overtake the release's write-back (no s_waitcnt vmcnt(0) in between)"
             check_signal(name, code, i, "mailbox flag")
             seen += 1
-    assert seen >= 15, f"only {seen} mailbox flags found"
+    assert seen >= 19, f"only {seen} mailbox flags found"
