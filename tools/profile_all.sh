@@ -3,10 +3,10 @@
 # Kernel-trace and PMC passes are separate runs, the PMC passes never carry a trace flag, and the profiled program follows `--`
 # directly (pool rules).  usage: tools/profile_all.sh [tags...]   (default: all)
 export TMPDIR=/tmp
-R=r02
+R=${R:-r03}
 prof() {   # tag workload size pmc? -- program args...
   local tag=$1 wl=$2 size=$3 pmc=$4; shift 5
-  local d=gpurun_out/prof_$tag; rm -rf $d; mkdir -p $d
+  local d=gpurun_out/prof_${R}_$tag; rm -rf $d; mkdir -p $d
   rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- "$@" > $d/out.json 2> $d/err1.log
   if [ "$pmc" = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/pmc_fetch -- "$@" > /dev/null 2> $d/err3.log
@@ -28,3 +28,6 @@ has hyrax_lookup && prof hyrax_lookup hyrax-lookup 4096x8192 1 -- $B --workload 
 has hyrax_bucket && prof hyrax_bucket hyrax-bucket 4096x8192 1 -- $B --workload hyrax --precompute-gb 0 --steps 8 --warmup 2
 has sumcheck && prof sumcheck sumcheck 18x2^21 1 -- python3 tools/bench_sumcheck.py 21 2
 has bullet && prof bullet bullet 8192 1 -- python3 tools/bench_bullet.py
+# round 3: the driver's own command (every block of the bench line) and the compiled prove-stages harness (kernel stats only)
+has bench && prof bench bench default 0 -- python3 bench.py
+has prove && prof prove prove keyless 0 -- python3 tools/trace_harness.py 2
