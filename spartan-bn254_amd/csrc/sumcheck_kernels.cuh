@@ -598,8 +598,8 @@ __global__ void __launch_bounds__(256) k_eq_direct(const uint32_t* __restrict__ 
 // hash layer: out[j] = (ts[j]+ts_add)*g^2 + val[j]*g + addr[j] - tau.  g2rr = g^2 * R (a "doubly Montgomery" value), so one
 // Montgomery product with the plain small integer ts gives mont(ts*g^2); rr = R^2 turns the plain addr into mont(addr).
 __global__ void __launch_bounds__(256) k_hash_layer(const uint32_t* __restrict__ addr, const uint32_t* __restrict__ val, const uint32_t* __restrict__ ts, uint32_t ts_add,
-                                                    const uint32_t* __restrict__ consts /* g, g2rr, tau : Montgomery */, size_t n, uint32_t* __restrict__ out) {
-  const Fr g = fe_load<FrP>(consts), g2rr = fe_load<FrP>(consts + 8), ntau = fe_load<FrP>(consts + 16);      // consts[2] = -tau (canonical)
+                                                    ScScalar g_m, ScScalar g2rr_m, ScScalar ntau_m /* g R, g^2 R^2, (r - tau) R: canonical, from the host */, size_t n, uint32_t* __restrict__ out) {
+  const Fr g = fr_from_words(g_m), g2rr = fr_from_words(g2rr_m), ntau = fr_from_words(ntau_m);
   const Fr rr = fe_const_r2<FrP>();
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
     const unsigned long long av = addr ? addr[j] : (unsigned long long)j;
@@ -615,7 +615,6 @@ __global__ void __launch_bounds__(256) k_product_layer(const uint32_t* __restric
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
     fe_store_tab<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
 }
-// g (canonical) -> {mont(g), g^2 * R^2 mod r (= mont(mont(g^2))), mont(tau)}
 // the top of a product tree in one launch: from a layer of `len` <= 2048 entries down to the single product, one block, one layer
 // after the other (out[k] has len >> (k+1) entries); saves ~10 launches per circuit, which is what the small layers cost
 constexpr int PT_TAIL_MAX = 12;
@@ -634,15 +633,6 @@ __global__ void __launch_bounds__(1024) k_product_tail(const uint32_t* __restric
     if (half == 1) break;
   }
 }
-__global__ void k_hash_consts(ScScalar g_canon, ScScalar tau_canon, uint32_t* __restrict__ consts) {
-  if (threadIdx.x || blockIdx.x) return;
-  const Fr g = fr_from_words(g_canon), t = fr_from_words(tau_canon);
-  const Fr gm = fe_to_mont(g), tm = fe_to_mont(t);
-  fe_store<FrP>(consts, gm);
-  fe_store<FrP>(consts + 8, fe_to_mont(fe_mul(gm, gm)));
-  fe_store<FrP>(consts + 16, fe_neg_lazy(tm));                  // -tau, canonical: the hash layer only adds
-}
-
 // one running sum per thread -> the block's sum in the 3-slot layout of k_sc_finish (slots 1, 2 zero)
 __device__ __forceinline__ void sc_block_sum1_store(Fr acc, uint32_t* __restrict__ o) {
   __shared__ uint32_t sm[4][NL];
