@@ -91,16 +91,14 @@ __device__ __forceinline__ void sc_lds_acc_add(ScLdsAcc& A, int t, const Fr& x, 
 // software pipeline as k_sc_bind_eval_pf).  Output: the block's three sums to partial[(slot * gridDim.x + blockIdx.x) * 3 + ..], folded
 // by the last block into mailbox slot `slot` (sc_last_block_fold's protocol; slot = the "instance" index the host waits on).
 template <bool SCALE>
-__global__ void __launch_bounds__(256, 2) k_sc_comb_bind_eval(const ScCombGroup* __restrict__ groups, size_t q, ScScalar rmont, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
-                                                              uint32_t* __restrict__ out, uint32_t slot0, uint32_t seq) {
-  const ScCombGroup* __restrict__ g = groups + blockIdx.y;
-  const Fr r = fr_from_words(rmont);
+__device__ __forceinline__ void sc_comb_bind_eval_body(const ScCombGroup* __restrict__ g, size_t q, const Fr& r, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
+                                                       uint32_t* __restrict__ out, uint32_t slot, uint32_t seq, uint32_t bidx, uint32_t nblk) {
   const uint32_t n = g->n;
   __shared__ ScLdsAcc acc;
   sc_lds_acc_zero(acc);
   uint32_t cnt = 0;
 #define SC_PIN() __builtin_amdgcn_sched_barrier(0)
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)bidx * blockDim.x + threadIdx.x; i < q; i += (size_t)nblk * blockDim.x) {
     Cols LL, HH, DD; cols_zero(LL); cols_zero(HH); cols_zero(DD);
     ScQuad zn = sc_quad_load<false>(g->a_src[0], i, q);
     uint32_t pend = 0;                                   // products in the column sums since the last carry pass
@@ -136,9 +134,42 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_bind_eval(const ScCombGroup*
   }
 #undef SC_PIN
   // the block's triple -> partial[slot][block], then the ticketed fold into the mailbox (sumcheck_kernels.cuh)
-  sc_block_sums_store_at(sc_lds_acc_get(acc, 0), sc_lds_acc_get(acc, 1), sc_lds_acc_get(acc, 2), partial, slot0 + blockIdx.y);
-  sc_last_block_fold_at(partial, tickets, out, 3, seq, slot0 + blockIdx.y);
+  sc_block_sums_store_at(sc_lds_acc_get(acc, 0), sc_lds_acc_get(acc, 1), sc_lds_acc_get(acc, 2), partial, slot, bidx, nblk);
+  sc_last_block_fold_at(partial, tickets, out, 3, seq, slot, nblk);
 }
+template <bool SCALE>
+__global__ void __launch_bounds__(256, 2) k_sc_comb_bind_eval(const ScCombGroup* __restrict__ groups, size_t q, ScScalar rmont, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
+                                                              uint32_t* __restrict__ out, uint32_t slot0, uint32_t seq) {
+  sc_comb_bind_eval_body<SCALE>(groups + blockIdx.y, q, fr_from_words(rmont), partial, tickets, out, slot0 + blockIdx.y, seq, blockIdx.x, gridDim.x);
+}
+
+// ---- one launch for a whole streaming round: the "par" groups AND the "seq" instances ------------------------------------------------
+// The combined kernel above is bound by its memory pattern (VALU ~40 % busy per wave), the per-instance streaming kernel of the "seq"
+// instances by the VALU (12 products per index pair).  Launched one after the other they add up; in ONE grid, with the two kinds of
+// block interleaved so that a CU holds one of each (both are 2-blocks-per-CU kernels), the VALU-bound blocks run in the memory-bound
+// blocks' shadow.  Block b of the 1-D grid is a "seq" block when floor((b + 1) Ts / T) > floor(b Ts / T) (Ts of the T blocks, evenly
+// spread); its index among its kind is dealt round-robin over the instances / groups.  Slots: seq instance j -> j, group g -> n_seq + g.
+template <bool SCALE>
+__global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __restrict__ groups, uint32_t n_groups, uint32_t gx_comb, ScFusedPack seqpack, uint32_t n_seq, uint32_t gx_seq, size_t q,
+                                                           ScScalar rmont, uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
+  const unsigned long long Ts = (unsigned long long)n_seq * gx_seq, T = Ts + (unsigned long long)n_groups * gx_comb, b = blockIdx.x;
+  const unsigned long long s0 = b * Ts / T, s1 = (b + 1) * Ts / T;
+  const Fr r = fr_from_words(rmont);
+  if (s1 > s0) {
+    const uint32_t inst = (uint32_t)(s0 % n_seq), bidx = (uint32_t)(s0 / n_seq);
+    ScFusedArgs a;
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)inst) a = seqpack.a[i];
+    Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+    sc_pf_body<KIND_CUBIC, 0>(a, q, r, e0, e2, e3, bidx, gx_seq);
+    sc_block_sums_store_slot(e0, e2, e3, true, partial_seq, nullptr, 0u, inst, bidx, gx_seq);
+    sc_last_block_fold_at(partial_seq, tickets, out, 3, seq, inst, gx_seq);
+  } else {
+    const uint32_t ci = (uint32_t)(b - s0), grp = ci % n_groups, bidx = ci / n_groups;
+    sc_comb_bind_eval_body<SCALE>(groups + grp, q, r, partial_comb, tickets, out, n_seq + grp, seq, bidx, gx_comb);
+  }
+}
+
 
 // ---- round 0 of the "par" group: the combined sums of the UNBOUND tables (no challenge yet) ---------------------------------------
 // A is scaled in registers when the tables are still unscaled (scale != 0: two products per instance), C = g->c is the table itself.
@@ -173,8 +204,8 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_eval(const ScCombGroup* __re
     const ScPts pc = sc_points_u(cl, ch);
     fr_acc32(e0, fe_mulu(S.s0, cl), c0); fr_acc32(e2, fe_mulu(S.s2, pc.v2), c2); fr_acc32(e3, fe_mulu(S.s3, pc.v3), c3);
   }
-  sc_block_sums_store_at(e0, e2, e3, partial, slot0 + blockIdx.y);
-  sc_last_block_fold_at(partial, tickets, out, 3, seq, slot0 + blockIdx.y);
+  sc_block_sums_store_at(e0, e2, e3, partial, slot0 + blockIdx.y, blockIdx.x, gridDim.x);
+  sc_last_block_fold_at(partial, tickets, out, 3, seq, slot0 + blockIdx.y, gridDim.x);
 }
 
 }  // namespace sbn

@@ -89,7 +89,8 @@ constexpr int SC_MBOX_WORDS = SC_MBOX_FINALS + (3 * SC_PACK_MAX + 8) * 8;
 // they go straight to the host mailbox as canonical integers and the flag follows — no partial sums, no ticket, no device fence.
 // Returns true when it finished the round that way.
 // slot = the "instance" index of the partial-sum / ticket / mailbox arrays (blockIdx.y for the per-instance kernels)
-__device__ __forceinline__ bool sc_block_sums_store_slot(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq, uint32_t slot) {
+// bidx / nblk: this block's index among the blocks that work for `slot`, and their number (blockIdx.x / gridDim.x in the one-kind kernels)
+__device__ __forceinline__ bool sc_block_sums_store_slot(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq, uint32_t slot, uint32_t bidx, uint32_t nblk) {
   __shared__ uint32_t sm[4][3][NL];
   e0 = wave_sum_fr(fe_reduce(e0)); e2 = wave_sum_fr(fe_reduce(e2));
   if (three) e3 = wave_sum_fr(fe_reduce(e3));
@@ -99,12 +100,12 @@ __device__ __forceinline__ bool sc_block_sums_store_slot(Fr e0, Fr e2, Fr e3, bo
     for (int k = 0; k < NL; k++) { sm[wv][0][k] = e0.v[k]; sm[wv][1][k] = e2.v[k]; sm[wv][2][k] = e3.v[k]; }
   }
   __syncthreads();
-  const bool direct = mbox != nullptr && gridDim.x == 1;
+  const bool direct = mbox != nullptr && nblk == 1;
   if (threadIdx.x < 3) {
     Fr s = fe_zero<FrP>();
     for (int w = 0; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][threadIdx.x][k]; s = fe_add(s, x); }
     if (direct) fe_store_packed<FrP>(mbox + 8 * ((size_t)slot * 3 + threadIdx.x), fe_from_mont(s));
-    else fr_store_coherent(partial + 8 * (((size_t)slot * gridDim.x + blockIdx.x) * 3 + threadIdx.x), fe_reduce(s));
+    else fr_store_coherent(partial + 8 * (((size_t)slot * nblk + bidx) * 3 + threadIdx.x), fe_reduce(s));
   }
   sc_drain_stores();                           // (wave 0 stored; the others have nothing outstanding) — before ANY barrier that precedes a signal
   if (direct) {
@@ -114,20 +115,20 @@ __device__ __forceinline__ bool sc_block_sums_store_slot(Fr e0, Fr e2, Fr e3, bo
   return direct;
 }
 __device__ __forceinline__ bool sc_block_sums_store(Fr e0, Fr e2, Fr e3, bool three, uint32_t* __restrict__ partial, uint32_t* __restrict__ mbox, uint32_t seq) {
-  return sc_block_sums_store_slot(e0, e2, e3, three, partial, mbox, seq, blockIdx.y);
+  return sc_block_sums_store_slot(e0, e2, e3, three, partial, mbox, seq, blockIdx.y, blockIdx.x, gridDim.x);
 }
-__device__ __forceinline__ void sc_block_sums_store_at(Fr e0, Fr e2, Fr e3, uint32_t* __restrict__ partial, uint32_t slot) {
-  sc_block_sums_store_slot(e0, e2, e3, true, partial, nullptr, 0u, slot);
+__device__ __forceinline__ void sc_block_sums_store_at(Fr e0, Fr e2, Fr e3, uint32_t* __restrict__ partial, uint32_t slot, uint32_t bidx, uint32_t nblk) {
+  sc_block_sums_store_slot(e0, e2, e3, true, partial, nullptr, 0u, slot, bidx, nblk);
 }
 // Called by all 256 threads after the block's triple went to partial[...] (several blocks per instance).  nq = 2 or 3.
 // `out` = mailbox in coherent pinned host memory: 24 x 96 B of results, then one flag word per instance; the flag is stored
 // (release, system scope) after the results, so the host can poll it instead of paying a stream synchronisation.
-__device__ __forceinline__ void sc_last_block_fold_at(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq, uint32_t slot) {
+__device__ __forceinline__ void sc_last_block_fold_at(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq, uint32_t slot, uint32_t nblk) {
   __shared__ uint32_t s_last;
   // The block's triple was written through to memory (fr_store_coherent) and its wave has waited for the acknowledgements
   // (sc_drain_stores at the end of sc_block_sums_store); behind the barrier one lane takes the ticket.  No L2 write-back anywhere.
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(&tickets[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1) ? 1u : 0u;
   __syncthreads();                             // the add has returned (its value was used) before any wave of the last block loads
   if (!s_last) return;
   // the partial sums are read with system-scope loads straight to registers (they bypass this CU's L1); the agent-scope acquire on
@@ -137,7 +138,7 @@ __device__ __forceinline__ void sc_last_block_fold_at(const uint32_t* __restrict
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (wv < 3) {
     Fr s = fe_zero<FrP>();
-    if (wv < nq) for (unsigned b = lane; b < gridDim.x; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)slot * gridDim.x + b) * 3 + wv)));
+    if (wv < nq) for (unsigned b = lane; b < nblk; b += 64) s = fe_add(s, fr_load_coherent(partial + 8 * (((size_t)slot * nblk + b) * 3 + wv)));
     s = wave_sum_fr(fe_reduce(s));
     if (lane == 0) fe_store_packed<FrP>(out + 8 * ((size_t)slot * 3 + wv), fe_from_mont(s));
   }
@@ -149,7 +150,7 @@ __device__ __forceinline__ void sc_last_block_fold_at(const uint32_t* __restrict
   }
 }
 __device__ __forceinline__ void sc_last_block_fold(const uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, int nq, uint32_t seq) {
-  sc_last_block_fold_at(partial, tickets, out, nq, seq, blockIdx.y);
+  sc_last_block_fold_at(partial, tickets, out, nq, seq, blockIdx.y, gridDim.x);
 }
 
 // The values of one table's line lo + t (hi - lo) at t = 2 and 3: p(2) = 2 hi - lo, p(3) = p(2) + hi - lo  (sumcheck.rs:111-135),
@@ -418,7 +419,7 @@ template <bool PRE> __device__ __forceinline__ ScPair sc_quad_bind(const ScQuad&
 }
 // table order: cubic 0,1,2 — r1cs 1,2,3,0 (tau last: tau * (Az*Bz - Cz)) — quad 0,1.  PREMASK bit t = the t-th table IN THAT ORDER is pre-bound.
 template <int KIND, int PREMASK>
-__device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const Fr& r, Fr& e0, Fr& e2, Fr& e3) {
+__device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const Fr& r, Fr& e0, Fr& e2, Fr& e3, uint32_t bidx, uint32_t nblk) {
   constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
   constexpr int T0 = KIND == KIND_R1CS ? 1 : 0, T1 = KIND == KIND_R1CS ? 2 : 1, T2 = KIND == KIND_R1CS ? 3 : 2, T3 = 0;
   constexpr bool P0 = (PREMASK & 1) != 0, P1 = (PREMASK & 2) != 0, P2 = (PREMASK & 4) != 0, P3 = (PREMASK & 8) != 0;
@@ -426,8 +427,8 @@ __device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const
   const uint32_t* s2 = a.src[NT > 2 ? T2 : T0]; const uint32_t* s3 = a.src[NT > 3 ? T3 : T0];
   uint32_t* d0 = a.dst[T0]; uint32_t* d1 = a.dst[T1];
   uint32_t* d2 = a.dst[NT > 2 ? T2 : T0]; uint32_t* d3 = a.dst[NT > 3 ? T3 : T0];
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)nblk * blockDim.x;
+  size_t i = (size_t)bidx * blockDim.x + threadIdx.x;
   if (i >= q) return;
   uint32_t c0 = 0, c2 = 0, c3 = 0;
   ScQuad zn = sc_quad_load<P0>(s0, i, q);
@@ -483,8 +484,8 @@ __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* _
   }
   const Fr r = fr_from_words(rmont);
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
-  if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3);   // "par" instance: the shared C arrives bound
-  else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3);
+  if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x);   // "par" instance: the shared C arrives bound
+  else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x);
   sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, nullptr, 0u);
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);     // (only the flag's system-scope release writes back: once per instance)
 }

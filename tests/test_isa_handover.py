@@ -44,7 +44,7 @@ def kernels():
         ins = line.split("//")[0].strip()
         if ins and re.match(r"^[a-z]", ins):
             out[cur].append(ins)
-    return {k: v for k, v in out.items() if re.search(r"k_sc_(eval|bind_eval|comb_eval|comb_bind_eval|finals)", k)}
+    return {k: v for k, v in out.items() if re.search(r"k_sc_(eval|bind_eval|comb_eval|comb_bind_eval|round_mixed|finals)", k)}
 
 
 def is_vm_store(ins):
