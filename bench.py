@@ -699,35 +699,33 @@ def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
         ms = res[mode]["ms_per_sumcheck"]
         res[mode]["algorithmic_GB"] = round(alg / 1e9, 3)
         res[mode]["GBps_end_to_end"] = round(alg / (ms * 1e-3) / 1e9, 1)
-    # the streaming rounds (tables of 2^16 entries and more): all three kernels that make up such a round
-    npf = max(0, logn - 15)
-    geo = sum(0.5 ** j for j in range(npf))
+    # the streaming rounds: ONE launch per round (k_sc_round_mixed: the "par" groups and the "seq" instances interleaved in one grid) + the
+    # out-of-place bind of the shared C ahead of it; the first launch (tables of 2^logn entries) is timed under its own name
     ks = res["stateful"]["kernels_ms_total"]; kl = res["stateful"]["kernels_launches"]
-    first_ms = ks.get("k_sc_comb_bind_eval_first", 0.0)               # the first bind (2^logn tables; it also folds coeffs into A) is timed under its own name
-    comb_ms, comb_n = ks.get("k_sc_comb_bind_eval", 0.0) + first_ms, kl.get("k_sc_comb_bind_eval", 0) + kl.get("k_sc_comb_bind_eval_first", 0)
-    stream_ms = comb_ms + ks.get("k_sc_bind_eval_cubic_stream", 0.0) + ks.get("k_bind_oop", 0.0)
+    first_ms = ks.get("k_sc_round_mixed_first", 0.0)
+    mix_ms, mix_n = ks.get("k_sc_round_mixed", 0.0) + first_ms, kl.get("k_sc_round_mixed", 0) + kl.get("k_sc_round_mixed_first", 0)
+    rest_comb_ms = ks.get("k_sc_comb_bind_eval", 0.0) + ks.get("k_sc_comb_bind_eval_first", 0.0) + ks.get("k_sc_bind_eval_cubic_stream", 0.0)
     small_ms = ks.get("k_sc_bind_eval_cubic", 0.0) + ks.get("k_bind_top", 0.0)
-    if stream_ms and npf and comb_n:
-        # the combined kernel runs on every round with >= 2^13 index pairs: comb_n launches, "par" tables + the bound shared C
-        geo_c = sum(0.5 ** j for j in range(comb_n))
-        alg_comb = (par_bytes * 1.5 + n * 32 * 0.5) * geo_c
-        ach_c = alg_comb / (comb_ms * 1e-3) / 1e9
-        alg_stream = table_bytes * 1.5 * geo + (alg_comb - (par_bytes * 1.5 + n * 32 * 0.5) * geo)     # + the combined kernel's launches below 2^16 entries
-        ach = alg_stream / (stream_ms * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_comb_bind_eval (the 12 'par' instances: bind + combined sums, one reduction per index)", "achieved": round(ach_c, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach_c / HBM_PEAK_GBS, 4), "traffic": None, "launches": comb_n, "kernel_avg_ms": round(comb_ms / comb_n, 4),
-                           "algorithmic_bytes_per_launch": int(alg_comb / comb_n), "kernel_ms_total": round(comb_ms, 3),
-                           "note": "kernel-only (HIP events on the context's stream), per launch averaged over its %d launches of one sumcheck (table bytes halve per round): 24 tables read once, bound halves written once, the bound shared C read once" % comb_n,
-                           "largest_launch": {"what": "the first bind: tables of 2^%d entries, 2^%d index pairs per instance" % (logn, logn - 2), "kernel_ms": round(first_ms, 4),
-                                              "algorithmic_bytes": int(par_bytes * 1.5 + n * 32 * 0.5), "GBps": round((par_bytes * 1.5 + n * 32 * 0.5) / (first_ms * 1e-3) / 1e9, 1) if first_ms else None,
-                                              "frac": round((par_bytes * 1.5 + n * 32 * 0.5) / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if first_ms else None},
-                           "streaming_rounds_all_kernels": {"kernels": "k_sc_comb_bind_eval + k_sc_bind_eval_pf<CUBIC> (the 6 'seq' instances) + k_bind_oop (shared C)", "kernel_ms": round(stream_ms, 3),
-                                                            "algorithmic_bytes": int(alg_stream), "GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
-                                                            "note": "every kernel of the rounds on tables of 2^16 entries and more (43 tables read once, bound halves written once); the figure round 2 reported as its roofline"},
-                           "all_fused_rounds": {"kernel_ms": round(stream_ms + small_ms, 3), "algorithmic_bytes": int(alg_fused_rounds),
-                                                "GBps": round(alg_fused_rounds / ((stream_ms + small_ms) * 1e-3) / 1e9, 1),
-                                                "note": "incl. the launch-latency-bound rounds on small tables"}}
-        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_comb_bind_eval")
+    if mix_ms and mix_n:
+        unit = n * 32                                                  # one table of the first round
+        per_round0 = ((2 * NPAR + 3 * NSEQ) * 1.5 + 0.5) * unit         # 42 tables read once, their bound halves written once, the bound shared C read once
+        geo = sum(0.5 ** j for j in range(mix_n))
+        alg_mix = per_round0 * geo
+        ach = alg_mix / (mix_ms * 1e-3) / 1e9
+        bind_c_ms = ks.get("k_bind_oop", 0.0)
+        alg_stream = table_bytes * 1.5 * geo                            # + the shared C's own bind (read 1, write 1/2)
+        res["roofline"] = {"bound": "hbm", "kernel": "k_sc_round_mixed (ONE launch per streaming round: 12 'par' instances on the combined code path + 6 'seq' instances, interleaved blocks)",
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": mix_n,
+                           "kernel_avg_ms": round(mix_ms / mix_n, 4), "algorithmic_bytes_per_launch": int(alg_mix / mix_n), "kernel_ms_total": round(mix_ms, 3),
+                           "note": "kernel-only (HIP events on the context's stream), per launch averaged over its %d launches of one sumcheck (table bytes halve per round)" % mix_n,
+                           "largest_launch": {"what": "the first bind: 42 tables of 2^%d entries (+ the bound shared C)" % logn, "kernel_ms": round(first_ms, 4), "algorithmic_bytes": int(per_round0),
+                                              "GBps": round(per_round0 / (first_ms * 1e-3) / 1e9, 1) if first_ms else None, "frac": round(per_round0 / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if first_ms else None},
+                           "streaming_rounds_all_kernels": {"kernels": "k_sc_round_mixed + k_bind_oop (shared C)", "kernel_ms": round(mix_ms + bind_c_ms, 3), "algorithmic_bytes": int(alg_stream),
+                                                            "GBps": round(alg_stream / ((mix_ms + bind_c_ms) * 1e-3) / 1e9, 1), "frac": round(alg_stream / ((mix_ms + bind_c_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                           "all_fused_rounds": {"kernel_ms": round(mix_ms + bind_c_ms + rest_comb_ms + small_ms, 3), "algorithmic_bytes": int(alg_fused_rounds),
+                                                "GBps": round(alg_fused_rounds / ((mix_ms + bind_c_ms + rest_comb_ms + small_ms) * 1e-3) / 1e9, 1),
+                                                "note": "incl. the rounds below 2^14 index pairs (combined / per-instance single-launch kernels, launch-latency bound)"}}
+        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_round_mixed")
         if st:
             res["roofline"]["traffic"] = int(st[0])
             res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per launch; not measured by this run)"

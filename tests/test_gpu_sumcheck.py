@@ -651,14 +651,15 @@ def test_stateful_sumcheck_combined_kernels(ctx, ol, logn, n_par, n_seq):
 
 def test_stateful_sumcheck_modes_agree(ctx, ol, pr):
     """a zero coefficient among the "par" instances (no inverse: nothing is scaled, the host weighs every triple), and SBN_SC_NO_COMB /
-    SBN_SC_NO_COMB_KERNEL forcing the other two modes onto a size the combined kernels would take: all equal to the oracle"""
+    SBN_SC_NO_COMB_KERNEL forcing the other two modes onto a size the combined kernels would take, SBN_SC_NO_MIXED the separate launches of
+    the "par" groups and the "seq" instances: all equal to the oracle"""
     import os
     co = bytearray(rand_scalars(8, 4242)); co[32:64] = bytes(32)
     _run_stateful_sumcheck(ctx, ol, 1 << 15, 5, 3, 7900, bytes(co))
     _run_stateful_sumcheck(ctx, ol, 1 << 6, 5, 3, 7910, bytes(co))
     one = (1).to_bytes(32, "little"); top = (pr.R - 1).to_bytes(32, "little")
     _run_stateful_sumcheck(ctx, ol, 1 << 15, 3, 1, 7920, one + top + one + top)              # coefficients 1 and r - 1
-    for var in ("SBN_SC_NO_COMB", "SBN_SC_NO_COMB_KERNEL"):
+    for var in ("SBN_SC_NO_COMB", "SBN_SC_NO_COMB_KERNEL", "SBN_SC_NO_MIXED"):
         os.environ[var] = "1"
         try:
             _run_stateful_sumcheck(ctx, ol, 1 << 16, 4, 2, 7930)

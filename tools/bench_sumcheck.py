@@ -109,7 +109,7 @@ def main():
     res["fused"]["kernel_only_rounds_ms"] = round(fused_ms, 3)
     res["fused"]["kernel_only_rounds_GBps"] = round(2 * table_bytes * 1.5 / (fused_ms * 1e-3) / 1e9, 1) if fused_ms else None
     ks = res["stateful"]["kernels_ms_total"]
-    st_stream = ks.get("k_sc_comb_bind_eval", 0.0) + ks.get("k_sc_comb_bind_eval_first", 0.0) + ks.get("k_sc_bind_eval_cubic_stream", 0.0) + ks.get("k_bind_oop", 0.0)
+    st_stream = ks.get("k_sc_round_mixed", 0.0) + ks.get("k_sc_round_mixed_first", 0.0) + ks.get("k_sc_comb_bind_eval", 0.0) + ks.get("k_sc_comb_bind_eval_first", 0.0) + ks.get("k_sc_bind_eval_cubic_stream", 0.0) + ks.get("k_bind_oop", 0.0)
     if st_stream and npf:
         res["stateful"]["streaming_rounds_ms"] = round(st_stream, 3)
         res["stateful"]["streaming_rounds_GBps"] = round(table_bytes * 1.5 * sum(0.5 ** j for j in range(npf)) / (st_stream * 1e-3) / 1e9, 1)
