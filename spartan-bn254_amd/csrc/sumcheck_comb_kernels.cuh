@@ -29,7 +29,6 @@ struct ScCombGroup {
   uint32_t* b_dst[SC_COMB_MAX];
   const uint32_t* c;                     // bind+eval kernel: the shared C ALREADY bound to this round's challenge (c[i], c[i + q]); eval kernel: C itself
   uint32_t n;                            // instances in the group
-  uint32_t src_tile, dst_tile;           // ScLayout of this launch (bind+eval kernel): the sources are TILE(q) tables, the bound tables are written TILE(q / 2)
   uint32_t scale;                        // 1: the A tables are still unscaled: the first bind writes A' = u z0 + v z2 (u = c_i (1 - r), v = c_i r); eval: A' = u A
   uint32_t u[SC_COMB_MAX][8], v[SC_COMB_MAX][8];   // Montgomery form, canonical
 };
@@ -95,41 +94,39 @@ template <bool SCALE>
 __device__ __forceinline__ void sc_comb_bind_eval_body(const ScCombGroup* __restrict__ g, size_t q, const Fr& r, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
                                                        uint32_t* __restrict__ out, uint32_t slot, uint32_t seq, uint32_t bidx, uint32_t nblk) {
   const uint32_t n = g->n;
-  const ScLayout ly = {g->src_tile, g->dst_tile};
   __shared__ ScLdsAcc acc;
   sc_lds_acc_zero(acc);
   uint32_t cnt = 0;
 #define SC_PIN() __builtin_amdgcn_sched_barrier(0)
   for (size_t i = (size_t)bidx * blockDim.x + threadIdx.x; i < q; i += (size_t)nblk * blockDim.x) {
     Cols LL, HH, DD; cols_zero(LL); cols_zero(HH); cols_zero(DD);
-    ScQuad zn = sc_quad_load<false>(g->a_src[0], i, q, ly);
-    const size_t wlo = tab_pos(ly.dst_tile, i, q / 2), whi = tab_pos(ly.dst_tile, i + q, q / 2);      // where this index's bound values go (and where the bound C lies)
+    ScQuad zn = sc_quad_load<false>(g->a_src[0], i, q);
     uint32_t pend = 0;                                   // products in the column sums since the last carry pass
     for (uint32_t k = 0; k < n; k++) {
       ScPair a, b;
       {
-        const ScQuad z = zn; zn = sc_quad_load<false>(g->b_src[k], i, q, ly); SC_PIN();
+        const ScQuad z = zn; zn = sc_quad_load<false>(g->b_src[k], i, q); SC_PIN();
         if (SCALE) {
           const Fr u = fr_load_uniform(g->u[k]), v = fr_load_uniform(g->v[k]);
           a.lo = sc_bind_scaled(z.z0, z.z2, u, v); a.hi = sc_bind_scaled(z.z1, z.z3, u, v);
         } else { a.lo = sc_bind1(z.z0, z.z2, r); a.hi = sc_bind1(z.z1, z.z3, r); }
         uint32_t* d = g->a_dst[k];
-        fe_gstore_packed<FrP>(d + 8 * wlo, a.lo); fe_gstore_packed<FrP>(d + 8 * whi, a.hi);
+        fe_gstore_packed<FrP>(d + 8 * i, a.lo); fe_gstore_packed<FrP>(d + 8 * (i + q), a.hi);
       }
       {
         const ScQuad z = zn;
         const uint32_t kn = k + 1 < n ? k + 1 : k;       // (the last step re-loads its own A: 4 of ~100 loads, L2 hits)
-        zn = sc_quad_load<false>(g->a_src[kn], i, q, ly); SC_PIN();
+        zn = sc_quad_load<false>(g->a_src[kn], i, q); SC_PIN();
         b.lo = sc_bind1(z.z0, z.z2, r); b.hi = sc_bind1(z.z1, z.z3, r);
         uint32_t* d = g->b_dst[k];
-        fe_gstore_packed<FrP>(d + 8 * wlo, b.lo); fe_gstore_packed<FrP>(d + 8 * whi, b.hi);
+        fe_gstore_packed<FrP>(d + 8 * i, b.lo); fe_gstore_packed<FrP>(d + 8 * (i + q), b.hi);
       }
       if (pend == 6) { cols_carry(LL); cols_carry(HH); cols_carry(DD); pend = 0; }
       pend++;
       const Fr da = fe_normu(fe_subb<FrP, 3, 1>(a.hi, a.lo)), db = fe_normu(fe_subb<FrP, 3, 1>(b.hi, b.lo));
       cols_mac<FrP>(LL, a.lo, b.lo); cols_mac<FrP>(HH, a.hi, b.hi); cols_mac<FrP>(DD, da, db);
     }
-    const Fr cl = fe_gload<FrP>(g->c + 8 * wlo), ch = fe_gload<FrP>(g->c + 8 * whi);
+    const Fr cl = fe_gload<FrP>(g->c + 8 * i), ch = fe_gload<FrP>(g->c + 8 * (i + q));
     const ScS S = sc_bracket_points(cols_reduce<FrP>(LL), cols_reduce<FrP>(HH), cols_reduce<FrP>(DD));
     const ScPts pc = sc_points_u(cl, ch);
     sc_lds_acc_add(acc, 0, fe_mulu(S.s0, cl), cnt); sc_lds_acc_add(acc, 1, fe_mulu(S.s2, pc.v2), cnt); sc_lds_acc_add(acc, 2, fe_mulu(S.s3, pc.v3), cnt);
@@ -154,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_bind_eval(const ScCombGroup*
 // spread); its index among its kind is dealt round-robin over the instances / groups.  Slots: seq instance j -> j, group g -> n_seq + g.
 template <bool SCALE>
 __global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __restrict__ groups, uint32_t n_groups, uint32_t gx_comb, ScFusedPack seqpack, uint32_t n_seq, uint32_t gx_seq, size_t q,
-                                                           ScScalar rmont, uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq, ScLayout ly) {
+                                                           ScScalar rmont, uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
   const unsigned long long Ts = (unsigned long long)n_seq * gx_seq, T = Ts + (unsigned long long)n_groups * gx_comb, b = blockIdx.x;
   const unsigned long long s0 = b * Ts / T, s1 = (b + 1) * Ts / T;
   const Fr r = fr_from_words(rmont);
@@ -164,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __
 #pragma unroll
     for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)inst) a = seqpack.a[i];
     Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
-    sc_pf_body<KIND_CUBIC, 0>(a, q, r, e0, e2, e3, bidx, gx_seq, ly);
+    sc_pf_body<KIND_CUBIC, 0>(a, q, r, e0, e2, e3, bidx, gx_seq);
     sc_block_sums_store_slot(e0, e2, e3, true, partial_seq, nullptr, 0u, inst, bidx, gx_seq);
     sc_last_block_fold_at(partial_seq, tickets, out, 3, seq, inst, gx_seq);
   } else {

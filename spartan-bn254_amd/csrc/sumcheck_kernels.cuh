@@ -235,21 +235,6 @@ struct ScFusedArgs {
 };
 struct ScFusedPack { ScFusedArgs a[SC_PACK_MAX]; };
 
-// ---- memory layout of a table inside a stateful sumcheck (the library's own buffers; the caller's tables are always plain) ----------
-// A streaming round touches, per index i < q of a table of 4 q entries, the elements i, i + q, i + 2q, i + 3q: four read streams q x 32 B
-// apart per table (and two write streams), 2 KiB per wavefront each.  In the TILE layout the element i + k q (k < 4) lives at
-//        (i / 64) * 256 + k * 64 + i % 64
-// i.e. the four 64-element pieces a wavefront needs are ONE contiguous 8-KiB group: one read stream per table (tools/micro/scbench:
-// the pure access pattern runs 4-9 % faster, and the round kernels are bound by exactly that pattern).  The bound table (2 q = 4 q'
-// entries, q' = q / 2) is written in the same layout for q', so the next round finds it tiled for ITS q.  Needs q' >= 64.
-struct ScLayout { uint32_t src_tile, dst_tile; };            // per launch, uniform
-// position of element m of a table whose quarter length is qq (a power of two)
-__device__ __forceinline__ size_t tab_pos(uint32_t tile, size_t m, size_t qq) {
-  if (!tile) return m;
-  const size_t j = m & (qq - 1), k = m >> __builtin_ctzll(qq);
-  return ((j >> 6) << 8) + (k << 6) + (j & 63);
-}
-
 // z0 + r (z2 - z0) as the table representative in [0, 2.5 r) that is stored and used: z0, z2 are table values (normalised,
 // below 2.5 r), their limb-wise difference is a legal product operand, the product lies in (-0.1 r, 1.1 r)
 // On the unsigned fast path: table values lie in [0, 2.5 r) (normalised), the difference carries 3r (below 5.5 r), the product of the
@@ -265,11 +250,11 @@ __device__ __forceinline__ Fr sc_bind1(const Fr& z0, const Fr& z2, const Fr& r) 
 }
 // one table at index i: bound values lo = Z'[i], hi = Z'[i + q]
 struct ScPair { Fr lo, hi; };
-__device__ __forceinline__ ScPair sc_bound_pair(const uint32_t* __restrict__ z, uint32_t* __restrict__ dst, uint32_t pre, size_t i, size_t q, const Fr& r, uint32_t src_tile = 0) {
+__device__ __forceinline__ ScPair sc_bound_pair(const uint32_t* __restrict__ z, uint32_t* __restrict__ dst, uint32_t pre, size_t i, size_t q, const Fr& r) {
   ScPair o;
   if (pre) { o.lo = fe_gload<FrP>(z + 8 * i); o.hi = fe_gload<FrP>(z + 8 * (i + q)); return o; }
-  const Fr z0 = fe_gload<FrP>(z + 8 * tab_pos(src_tile, i, q)), z2 = fe_gload<FrP>(z + 8 * tab_pos(src_tile, i + 2 * q, q));
-  const Fr z1 = fe_gload<FrP>(z + 8 * tab_pos(src_tile, i + q, q)), z3 = fe_gload<FrP>(z + 8 * tab_pos(src_tile, i + 3 * q, q));
+  const Fr z0 = fe_gload<FrP>(z + 8 * i), z2 = fe_gload<FrP>(z + 8 * (i + 2 * q));
+  const Fr z1 = fe_gload<FrP>(z + 8 * (i + q)), z3 = fe_gload<FrP>(z + 8 * (i + 3 * q));
   o.lo = sc_bind1(z0, z2, r);
   o.hi = sc_bind1(z1, z3, r);
   if (dst) { fe_gstore_packed<FrP>(dst + 8 * i, o.lo); fe_gstore_packed<FrP>(dst + 8 * (i + q), o.hi); }
@@ -297,7 +282,7 @@ __device__ __forceinline__ void sc_minus(ScProd& P, const ScPair& t) {       // 
 // WPS = waves per SIMD the register allocation is held to
 template <int KIND, int WPS>
 __global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial,
-                                                      uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq, uint32_t src_tile /* the sources are TILE(q) tables of a stateful sumcheck */) {
+                                                      uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
   ScFusedArgs a;
   if (args) a = args[blockIdx.y];
   else {
@@ -308,7 +293,7 @@ __global__ void __launch_bounds__(256, WPS) k_sc_bind_eval(const ScFusedArgs* __
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   uint32_t c0 = 0, c2 = 0, c3 = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
-#define SC_TAB(j) sc_bound_pair(a.src[j], a.dst[j], a.pre[j], i, q, r, src_tile)
+#define SC_TAB(j) sc_bound_pair(a.src[j], a.dst[j], a.pre[j], i, q, r)
     ScProd P;
     if (KIND == KIND_QUAD) {
       { const ScPair t = SC_TAB(0); sc_first<KIND>(P, t); }
@@ -418,25 +403,23 @@ __global__ void __launch_bounds__(512) k_sc_bind_eval_tiny(const ScFusedArgs* __
 // "prefetch" back down to its use (seen in the ISA), which is exactly the serial load -> wait -> compute chain this form removes.
 // A table that is not pre-bound always has its writer here (the host pre-binds every shared table on this path).
 struct ScQuad { Fr z0, z1, z2, z3; };     // the four elements of one table at index i (pre-bound table: z0 = lo, z1 = hi)
-// (a pre-bound table is the DESTINATION-layout table of this round: 2 q entries, quarter length q / 2)
-template <bool PRE> __device__ __forceinline__ ScQuad sc_quad_load(const uint32_t* __restrict__ z, size_t i, size_t q, ScLayout ly = ScLayout{0, 0}) {
+template <bool PRE> __device__ __forceinline__ ScQuad sc_quad_load(const uint32_t* __restrict__ z, size_t i, size_t q) {
   ScQuad o;
-  if (PRE) { o.z0 = fe_gload<FrP>(z + 8 * tab_pos(ly.dst_tile, i, q / 2)); o.z1 = fe_gload<FrP>(z + 8 * tab_pos(ly.dst_tile, i + q, q / 2)); return o; }
-  o.z0 = fe_gload<FrP>(z + 8 * tab_pos(ly.src_tile, i, q)); o.z1 = fe_gload<FrP>(z + 8 * tab_pos(ly.src_tile, i + q, q));
-  o.z2 = fe_gload<FrP>(z + 8 * tab_pos(ly.src_tile, i + 2 * q, q)); o.z3 = fe_gload<FrP>(z + 8 * tab_pos(ly.src_tile, i + 3 * q, q));
+  o.z0 = fe_gload<FrP>(z + 8 * i); o.z1 = fe_gload<FrP>(z + 8 * (i + q));
+  if (!PRE) { o.z2 = fe_gload<FrP>(z + 8 * (i + 2 * q)); o.z3 = fe_gload<FrP>(z + 8 * (i + 3 * q)); }
   return o;
 }
-template <bool PRE> __device__ __forceinline__ ScPair sc_quad_bind(const ScQuad& z, uint32_t* __restrict__ dst, size_t i, size_t q, const Fr& r, ScLayout ly = ScLayout{0, 0}) {
+template <bool PRE> __device__ __forceinline__ ScPair sc_quad_bind(const ScQuad& z, uint32_t* __restrict__ dst, size_t i, size_t q, const Fr& r) {
   ScPair o;
   if (PRE) { o.lo = z.z0; o.hi = z.z1; return o; }
   o.lo = sc_bind1(z.z0, z.z2, r);
   o.hi = sc_bind1(z.z1, z.z3, r);
-  fe_gstore_packed<FrP>(dst + 8 * tab_pos(ly.dst_tile, i, q / 2), o.lo); fe_gstore_packed<FrP>(dst + 8 * tab_pos(ly.dst_tile, i + q, q / 2), o.hi);
+  fe_gstore_packed<FrP>(dst + 8 * i, o.lo); fe_gstore_packed<FrP>(dst + 8 * (i + q), o.hi);
   return o;
 }
 // table order: cubic 0,1,2 — r1cs 1,2,3,0 (tau last: tau * (Az*Bz - Cz)) — quad 0,1.  PREMASK bit t = the t-th table IN THAT ORDER is pre-bound.
 template <int KIND, int PREMASK>
-__device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const Fr& r, Fr& e0, Fr& e2, Fr& e3, uint32_t bidx, uint32_t nblk, ScLayout ly = ScLayout{0, 0}) {
+__device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const Fr& r, Fr& e0, Fr& e2, Fr& e3, uint32_t bidx, uint32_t nblk) {
   constexpr int NT = KIND == KIND_QUAD ? 2 : KIND == KIND_CUBIC ? 3 : 4;
   constexpr int T0 = KIND == KIND_R1CS ? 1 : 0, T1 = KIND == KIND_R1CS ? 2 : 1, T2 = KIND == KIND_R1CS ? 3 : 2, T3 = 0;
   constexpr bool P0 = (PREMASK & 1) != 0, P1 = (PREMASK & 2) != 0, P2 = (PREMASK & 4) != 0, P3 = (PREMASK & 8) != 0;
@@ -448,7 +431,7 @@ __device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const
   size_t i = (size_t)bidx * blockDim.x + threadIdx.x;
   if (i >= q) return;
   uint32_t c0 = 0, c2 = 0, c3 = 0;
-  ScQuad zn = sc_quad_load<P0>(s0, i, q, ly);
+  ScQuad zn = sc_quad_load<P0>(s0, i, q);
   // the scheduler otherwise moves every prefetch down to its first use (fewer live registers, and the serial chain back):
   // nothing crosses SC_PIN, so the loads stay issued ahead of the arithmetic of the stage they overlap
 #define SC_PIN() __builtin_amdgcn_sched_barrier(0)
@@ -457,28 +440,28 @@ __device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const
     const size_t ipre = inext < q ? inext : i;          // the last iteration re-loads its own first table (harmless) instead of branching
     ScProd P;
     {
-      const ScQuad z = zn; zn = sc_quad_load<P1>(s1, i, q, ly); SC_PIN();
-      const ScPair t = sc_quad_bind<P0>(z, d0, i, q, r, ly);
+      const ScQuad z = zn; zn = sc_quad_load<P1>(s1, i, q); SC_PIN();
+      const ScPair t = sc_quad_bind<P0>(z, d0, i, q, r);
       sc_first<KIND>(P, t);
     }
     {
       const ScQuad z = zn;
-      if (NT > 2) zn = sc_quad_load<P2>(s2, i, q, ly); else zn = sc_quad_load<P0>(s0, ipre, q, ly);
+      if (NT > 2) zn = sc_quad_load<P2>(s2, i, q); else zn = sc_quad_load<P0>(s0, ipre, q);
       SC_PIN();
-      const ScPair t = sc_quad_bind<P1>(z, d1, i, q, r, ly);
+      const ScPair t = sc_quad_bind<P1>(z, d1, i, q, r);
       sc_times<KIND>(P, t);
     }
     if (NT > 2) {
       const ScQuad z = zn;
-      if (NT > 3) zn = sc_quad_load<P3>(s3, i, q, ly); else zn = sc_quad_load<P0>(s0, ipre, q, ly);
+      if (NT > 3) zn = sc_quad_load<P3>(s3, i, q); else zn = sc_quad_load<P0>(s0, ipre, q);
       SC_PIN();
-      const ScPair t = sc_quad_bind<P2>(z, d2, i, q, r, ly);
+      const ScPair t = sc_quad_bind<P2>(z, d2, i, q, r);
       if (KIND == KIND_CUBIC) sc_times<KIND>(P, t); else sc_minus(P, t);
     }
     if (NT > 3) {
       const ScQuad z = zn;
-      zn = sc_quad_load<P0>(s0, ipre, q, ly); SC_PIN();
-      const ScPair t = sc_quad_bind<P3>(z, d3, i, q, r, ly);
+      zn = sc_quad_load<P0>(s0, ipre, q); SC_PIN();
+      const ScPair t = sc_quad_bind<P3>(z, d3, i, q, r);
       sc_times<KIND>(P, t);
     }
     fr_acc(e0, P.p0, c0); fr_acc(e2, P.p2, c2);
@@ -492,7 +475,7 @@ __device__ __forceinline__ void sc_pf_body(const ScFusedArgs& a, size_t q, const
 __host__ __device__ inline bool sc_pf_mask_supported(int kind, unsigned mask) { return mask == 0 || (kind == KIND_CUBIC && mask == 4u); }
 template <int KIND>
 __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* __restrict__ args, ScFusedPack pack, size_t q /* old_len / 4 */, ScScalar rmont /* Montgomery form */, uint32_t* __restrict__ partial,
-                                                            uint32_t* __restrict__ tickets /* null: the caller runs k_sc_finish */, uint32_t* __restrict__ out, uint32_t seq, ScLayout ly) {
+                                                            uint32_t* __restrict__ tickets /* null: the caller runs k_sc_finish */, uint32_t* __restrict__ out, uint32_t seq) {
   ScFusedArgs a;
   if (args) a = args[blockIdx.y];
   else {
@@ -501,20 +484,19 @@ __global__ void __launch_bounds__(256, 2) k_sc_bind_eval_pf(const ScFusedArgs* _
   }
   const Fr r = fr_from_words(rmont);
   Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
-  if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x, ly);   // "par" instance: the shared C arrives bound
-  else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x, ly);
+  if (KIND == KIND_CUBIC && a.pre[2]) sc_pf_body<KIND, (KIND == KIND_CUBIC ? 4 : 0)>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x);   // "par" instance: the shared C arrives bound
+  else sc_pf_body<KIND, 0>(a, q, r, e0, e2, e3, blockIdx.x, gridDim.x);
   sc_block_sums_store(e0, e2, e3, KIND != KIND_QUAD, partial, nullptr, 0u);
   if (tickets) sc_last_block_fold(partial, tickets, out, KIND == KIND_QUAD ? 2 : 3, seq);     // (only the flag's system-scope release writes back: once per instance)
 }
 
 // out-of-place bind of the top variable of ONE table: dst[i] = Z[i] + r (Z[i + half] - Z[i]), i < half.  Runs ahead of a fused
 // round for a table that several instances of the round share (see ScFusedArgs::pre).
-// (ly: the layouts of Z — quarter length half / 2 — and of dst — quarter length half / 4 — inside a stateful sumcheck; {0, 0} = plain)
-__global__ void __launch_bounds__(256) k_bind_oop(const uint32_t* __restrict__ Z, uint32_t* __restrict__ dst, size_t half, ScScalar rmont, ScLayout ly) {
+__global__ void __launch_bounds__(256) k_bind_oop(const uint32_t* __restrict__ Z, uint32_t* __restrict__ dst, size_t half, ScScalar rmont) {
   const Fr r = fr_from_words(rmont);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    const Fr lo = fe_load<FrP>(Z + 8 * tab_pos(ly.src_tile, i, half / 2)), hi = fe_load<FrP>(Z + 8 * tab_pos(ly.src_tile, i + half, half / 2));
-    fe_store_packed<FrP>(dst + 8 * tab_pos(ly.dst_tile, i, half / 4), sc_bind1(lo, hi, r));
+    const Fr lo = fe_load<FrP>(Z + 8 * i), hi = fe_load<FrP>(Z + 8 * (i + half));
+    fe_store_packed<FrP>(dst + 8 * i, sc_bind1(lo, hi, r));
   }
 }
 
