@@ -725,9 +725,12 @@ def sumcheck_block(ctx, sbn, ol, torch, dev, logn):
                            "all_fused_rounds": {"kernel_ms": round(mix_ms + bind_c_ms + rest_comb_ms + small_ms, 3), "algorithmic_bytes": int(alg_fused_rounds),
                                                 "GBps": round(alg_fused_rounds / ((mix_ms + bind_c_ms + rest_comb_ms + small_ms) * 1e-3) / 1e9, 1),
                                                 "note": "incl. the rounds below 2^14 index pairs (combined / per-instance single-launch kernels, launch-latency bound)"}}
-        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_round_mixed")
+        st = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_round_mixed<*>") or stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_round_mixed")
         if st:
             res["roofline"]["traffic"] = int(st[0])
+            st1 = stored_traffic("sumcheck", "18x2^%d" % logn, "k_sc_round_mixed<true>")
+            if st1:
+                res["roofline"]["largest_launch"]["traffic"] = int(st1[0])
             res["roofline"]["traffic_source"] = st[1] + " (stored rocprofv3 --pmc passes of tools/bench_sumcheck.py at this size: average per launch; not measured by this run)"
     ke = res["separate"]["kernels_ms_total"]
     if ke.get("k_sc_eval_cubic") and ke.get("k_bind_top"):

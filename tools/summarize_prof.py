@@ -72,6 +72,18 @@ def main():
         base = k.split("<")[0]
         allt["entries"].append({"workload": workload, "size": size, "kernel": base if base != k and not any(e for e in allt["entries"] if e["workload"] == workload and e["size"] == size and e["kernel"] == base) else k,
                                 "kernel_full": k, "hbm_bytes_per_launch": b, "source": f"profiles/{tag}_pmc.csv"})
+    # launch-weighted average over the template variants of one kernel (e.g. k_sc_round_mixed<true> = the first, scaled launch of a
+    # sumcheck and <false> = the later rounds): the figure that pairs with a per-launch average over ALL launches of the kernel
+    variants = defaultdict(list)
+    for k in traffic:
+        if "<" in k:
+            variants[k.split("<")[0]].append(k)
+    for base, ks in sorted(variants.items()):
+        if len(ks) > 1:
+            nl = sum(cnts[k]["FETCH_SIZE"] for k in ks)
+            b = sum(traffic[k] * cnts[k]["FETCH_SIZE"] for k in ks) / max(nl, 1)
+            allt["entries"].append({"workload": workload, "size": size, "kernel": base + "<*>", "kernel_full": " + ".join(sorted(ks)), "launches": nl,
+                                    "hbm_bytes_per_launch": round(b), "source": f"profiles/{tag}_pmc.csv"})
     allt["note"] = "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes (gfx950: FETCH_SIZE counts 64 B per 128-B request); averaged over every launch of the kernel in the run, setup launches included"
     json.dump(allt, open(tj, "w"), indent=1)
     print("updated profiles/pmc_traffic.json")
