@@ -132,6 +132,9 @@ void sbn_table_free(sbn_ctx* ctx, sbn_table* t);
 size_t sbn_table_len(const sbn_table* t);                                   /* current len (halves per bind) */
 int sbn_table_download(sbn_ctx* ctx, const sbn_table* t, uint8_t* out /* len x 32 canonical */);
 int sbn_table_read0(sbn_ctx* ctx, const sbn_table* t, uint8_t out[32]);     /* poly[0] after the last round (sumcheck.rs:157) */
+/* the same for `count` tables in one launch and one wait (out: count x 32 bytes): the products of several product circuits
+ * (ProductCircuit::evaluate, product_tree.rs:59-64, called per circuit at sparse_mlpoly_full.rs:1326-1345) after all of them were enqueued */
+int sbn_table_read0_many(sbn_ctx* ctx, const sbn_table* const* ts, size_t count, uint8_t* out);
 /* DensePolynomial::bound_poly_var_top(r) (hyrax.rs:195-203) */
 int sbn_bind_top(sbn_ctx* ctx, sbn_table* t, const uint8_t r[32]);
 int sbn_bind_top_many(sbn_ctx* ctx, sbn_table* const* ts, size_t count, const uint8_t r[32]);

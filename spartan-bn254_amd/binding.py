@@ -12,7 +12,7 @@ EXPORTED_SYMBOLS = [
     "sbn_dev_alloc", "sbn_dev_free", "sbn_dev_upload", "sbn_dev_download",
     "sbn_msm", "sbn_msm_jacobian", "sbn_bases_split_at", "sbn_bases_scale", "sbn_bases_upload", "sbn_bases_precompute", "sbn_bases_free", "sbn_bases_len", "sbn_gens_new", "sbn_bases_synthetic", "sbn_scalars_synthetic", "sbn_bases_download",
     "sbn_msm_bases", "sbn_msm_bases_dev", "sbn_commit_rows", "sbn_commit_rows_dev", "sbn_g1_compress", "sbn_g1_sum", "sbn_unipoly_from_evals", "sbn_unipoly_eval", "sbn_factored_lens",
-    "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0",
+    "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0", "sbn_table_read0_many",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
     "sbn_sumcheck_begin", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
@@ -452,6 +452,13 @@ class Context:
 
     def table_read0(self, t):
         out = (C.c_uint8 * 32)(); self._chk(lib().sbn_table_read0(self.h, t.h, out), "sbn_table_read0"); return bytes(out)
+
+    def table_read0_many(self, ts):
+        """entry 0 of every table in `ts`: one launch, one wait (sbn_table_read0_many)"""
+        n = len(ts)
+        arr = (C.c_void_p * max(n, 1))(*[t.h for t in ts]); out = (C.c_uint8 * (32 * max(n, 1)))()
+        self._chk(lib().sbn_table_read0_many(self.h, arr, C.c_size_t(n), out), "sbn_table_read0_many")
+        return [bytes(out[32 * i:32 * i + 32]) for i in range(n)]
 
     def bind_top(self, t, r):
         self._chk(lib().sbn_bind_top(self.h, t.h, _ptr(r)), "sbn_bind_top")

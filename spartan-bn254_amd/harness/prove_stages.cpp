@@ -337,14 +337,16 @@ struct Harness {
           sbn_table_free(ctx, val);
         }
       }
-      std::vector<uint8_t> prods;
+      std::vector<sbn_table*> tops;                                        // all 16 circuits are enqueued, then their products come back in one wait
       for (auto* grp : {&ops_circ, &mem_circ}) for (auto& c : *grp) {
         sbn_table* layers[48]; size_t cnt = 0;
         chk(sbn_product_circuit(ctx, c[0], layers, 48, &cnt), "product_circuit");
         for (size_t j = 0; j + 1 < cnt; j++) c.push_back(layers[j]);
-        uint8_t top[32]; chk(sbn_table_read0(ctx, layers[cnt - 1], top), "read0 product"); prods.insert(prods.end(), top, top + 32);
-        sbn_table_free(ctx, layers[cnt - 1]);                             // the single-entry layer is the product itself (ProductCircuit::evaluate)
+        tops.push_back(layers[cnt - 1]);                                  // the single-entry layer is the product itself (ProductCircuit::evaluate)
       }
+      std::vector<uint8_t> prods(32 * tops.size());
+      chk(sbn_table_read0_many(ctx, tops.data(), tops.size(), prods.data()), "read0 products");
+      for (sbn_table* x : tops) sbn_table_free(ctx, x);
       absorb(0x03, prods.data(), prods.size());                           // claim_row_eval_* / claim_col_eval_* (sparse_mlpoly_full.rs:1326-1345)
     }
 

@@ -126,6 +126,21 @@ def test_full_prove_cubic_loop_fused(ctx, ol, pr):
         else:
             ctx.bind_top_many(ts, r)          # last round: nothing left to evaluate
     assert [ctx.table_read0(t) for t in ts] == [h[:32] for h in hs]
+    assert ctx.table_read0_many(ts) == [h[:32] for h in hs]
+    for t in ts:
+        t.free()
+
+
+def test_read0_many(ctx, sbn):
+    """sbn_table_read0_many: entry 0 of many separate tables in one launch (more than one 64-table chunk; empty list; null table)"""
+    tabs = [rand_scalars(1 << (i % 4), 900 + i) for i in range(70)]
+    ts = [ctx.table_upload(x) for x in tabs]
+    assert ctx.table_read0_many(ts) == [x[:32] for x in tabs]
+    assert ctx.table_read0_many(ts[:1]) == [tabs[0][:32]]
+    assert ctx.table_read0_many([]) == []
+    import ctypes as C
+    arr = (C.c_void_p * 2)(ts[0].h, None); out = (C.c_uint8 * 64)()
+    assert sbn.binding.lib().sbn_table_read0_many(ctx.h, arr, C.c_size_t(2), out) != 0
     for t in ts:
         t.free()
 
