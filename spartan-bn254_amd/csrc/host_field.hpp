@@ -172,13 +172,35 @@ static inline El mmul(const El& a, const El& b) {
 static inline El to_m(const El& a) { El r2; memcpy(r2.v, R2, 32); return mmul(a, r2); }                 // a * 2^256
 static inline El from_m(const El& a) { return mmul(a, from_u64(1)); }
 static inline bool is_zero(const El& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
-// 1 / a for a != 0, canonical in and out (Fermat; a few hundred products: once per sumcheck, never per round)
-static inline El inv(const El& a) {
+// 1 / a for a != 0, canonical in and out: the binary extended Euclid on 4 limbs (u, v shrink by shifts and subtractions while
+// b * a = u and c * a = v mod r are kept; ~2 x 254 steps, 2-3 us against ~20 us for Fermat's 380 Montgomery products).  Variable
+// time: the operands here are transcript challenges and batching coefficients, public values.  0 has no inverse: returns 0.
+static inline El inv_fermat(const El& a) {
   const uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
   const El am = to_m(a);
   El acc = to_m(from_u64(1));
   for (int i = 255; i >= 0; i--) { acc = mmul(acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mmul(acc, am); }
   return from_m(acc);
+}
+static inline El inv(const El& a) {
+  if (is_zero(a)) return a;
+  auto is_one = [](const uint64_t x[4]) { return x[0] == 1 && (x[1] | x[2] | x[3]) == 0; };
+  auto shr1 = [](uint64_t x[4], uint64_t top) { x[0] = (x[0] >> 1) | (x[1] << 63); x[1] = (x[1] >> 1) | (x[2] << 63); x[2] = (x[2] >> 1) | (x[3] << 63); x[3] = (x[3] >> 1) | (top << 63); };
+  auto halve = [&](uint64_t x[4]) {                       // x / 2 mod r for x < r: (x + r) / 2 when x is odd (x + r < 2^255)
+    uint64_t c = 0;
+    if (x[0] & 1) { for (int i = 0; i < 4; i++) { u128 s = (u128)x[i] + P[i] + c; x[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+    shr1(x, c);
+  };
+  auto lt = [](const uint64_t x[4], const uint64_t y[4]) { for (int i = 3; i >= 0; i--) { if (x[i] < y[i]) return true; if (x[i] > y[i]) return false; } return false; };
+  auto sub_raw = [](uint64_t x[4], const uint64_t y[4]) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)x[i] - y[i] - br; x[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } };
+  uint64_t u[4] = {a.v[0], a.v[1], a.v[2], a.v[3]}, v[4] = {P[0], P[1], P[2], P[3]};
+  El b = from_u64(1), c = from_u64(0);
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) { shr1(u, 0); halve(b.v); }
+    while (!(v[0] & 1)) { shr1(v, 0); halve(c.v); }
+    if (lt(v, u)) { sub_raw(u, v); b = sub(b, c); } else { sub_raw(v, u); c = sub(c, b); }
+  }
+  return is_one(u) ? b : c;
 }
 // canonical x -> the device's table representation x * 2^261 mod r (fp.cuh's Montgomery domain), canonical
 static inline El to_dev_mont(const El& x) {

@@ -77,13 +77,31 @@ El mmul(const El& a, const El& b) {
   if (t[4] || geq_r(r.v)) sub_r(r.v);
   return r;
 }
-El fr_inv(const El& a) {          // canonical in, canonical out
-  El r2; memcpy(r2.v, RR2, 32);
-  const El am = mmul(a, r2);
-  El one = {{1, 0, 0, 0}}, acc = mmul(one, r2);
-  const uint64_t e[4] = {RP[0] - 2, RP[1], RP[2], RP[3]};
-  for (int i = 255; i >= 0; i--) { acc = mmul(acc, acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mmul(acc, am); }
-  return mmul(acc, one);
+// canonical in, canonical out; a != 0.  The binary extended Euclid ark-ff's Field::inverse uses (variable time, public challenges):
+// b a = u, c a = v mod r while u, v shrink by shifts and subtractions.  A few microseconds, as on the Rust side.
+El fr_inv(const El& a) {
+  auto is_one = [](const uint64_t x[4]) { return x[0] == 1 && (x[1] | x[2] | x[3]) == 0; };
+  auto shr1 = [](uint64_t x[4], uint64_t top) { x[0] = (x[0] >> 1) | (x[1] << 63); x[1] = (x[1] >> 1) | (x[2] << 63); x[2] = (x[2] >> 1) | (x[3] << 63); x[3] = (x[3] >> 1) | (top << 63); };
+  auto halve = [&](uint64_t x[4]) {
+    uint64_t c = 0;
+    if (x[0] & 1) for (int i = 0; i < 4; i++) { u128 s = (u128)x[i] + RP[i] + c; x[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    shr1(x, c);
+  };
+  auto lt = [](const uint64_t x[4], const uint64_t y[4]) { for (int i = 3; i >= 0; i--) { if (x[i] < y[i]) return true; if (x[i] > y[i]) return false; } return false; };
+  auto sub_raw = [](uint64_t x[4], const uint64_t y[4]) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)x[i] - y[i] - br; x[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } };
+  auto sub_mod = [&](uint64_t x[4], const uint64_t y[4]) {       // x <- x - y mod r, both < r
+    if (lt(x, y)) { uint64_t c = 0; uint64_t t[4]; for (int i = 0; i < 4; i++) { u128 s2 = (u128)x[i] + RP[i] + c; t[i] = (uint64_t)s2; c = (uint64_t)(s2 >> 64); } sub_raw(t, y); memcpy(x, t, 32); }
+    else sub_raw(x, y);
+  };
+  uint64_t u[4] = {a.v[0], a.v[1], a.v[2], a.v[3]}, v[4] = {RP[0], RP[1], RP[2], RP[3]};
+  if ((u[0] | u[1] | u[2] | u[3]) == 0) return a;
+  El b = {{1, 0, 0, 0}}, c = {{0, 0, 0, 0}};
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) { shr1(u, 0); halve(b.v); }
+    while (!(v[0] & 1)) { shr1(v, 0); halve(c.v); }
+    if (lt(v, u)) { sub_raw(u, v); sub_mod(b.v, c.v); } else { sub_raw(v, u); sub_mod(c.v, b.v); }
+  }
+  return is_one(u) ? b : c;
 }
 // 32 hash bytes -> a canonical scalar: the top two bits cut, minus r when still >= r (uniform enough for a stand-in)
 void reduce_to_fr(uint8_t b[32]) { uint64_t v[4]; memcpy(v, b, 32); v[3] &= 0x3fffffffffffffffull; if (geq_r(v)) sub_r(v); memcpy(b, v, 32); }

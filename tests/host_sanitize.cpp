@@ -18,6 +18,19 @@ int main() {
   if (!eq(mul(a, inv(a)), one())) { printf("inv\n"); bad++; }
   if (!eq(sub(add(a, b), b), a)) { printf("addsub\n"); bad++; }
   if (!eq(from_mont(to_mont(Fq{{9, 8, 7, 6}})), Fq{{9, 8, 7, 6}})) { printf("mont\n"); bad++; }
+  // scalar field: the binary-Euclid inverse against Fermat's, and a * 1/a = 1, on edge values and a pseudo-random walk
+  {
+    using namespace sbn_host::fr;
+    El x = {{0x9E3779B97F4A7C15ull, 0xBF58476D1CE4E5B9ull, 0x94D049BB133111EBull, 0x0123456789abcdefull}};
+    El pm1 = {{P[0] - 1, P[1], P[2], P[3]}}, two = from_u64(2), big = {{0, 0, 0, 1ull << 60}};
+    std::vector<El> xs = {from_u64(1), two, pm1, big, from_u64(0xffffffffffffffffull)};
+    for (int i = 0; i < 200; i++) { x = mmul(x, x); x = add(x, from_u64(i + 1)); xs.push_back(x); }
+    for (const El& e : xs) {
+      const El i1 = inv(e), i2 = inv_fermat(e), pr = mmul(to_m(e), i1);
+      if (memcmp(i1.v, i2.v, 32) || !(pr.v[0] == 1 && (pr.v[1] | pr.v[2] | pr.v[3]) == 0) || geq(i1.v)) { printf("fr inv\n"); bad++; break; }
+    }
+    if (!is_zero(inv(from_u64(0)))) { printf("fr inv 0\n"); bad++; }
+  }
   // group law: 2G+3G == 5G, P + (-P) == inf, window combine == scalar multiple
   Pt G = gen();
   uint8_t x1[64], x2[64]; int i1 = 0, i2 = 0;
