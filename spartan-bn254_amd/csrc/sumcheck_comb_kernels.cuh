@@ -151,10 +151,12 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_bind_eval(const ScCombGroup*
 // spread); its index among its kind is dealt round-robin over the instances / groups.  Slots: seq instance j -> j, group g -> n_seq + g.
 template <bool SCALE>
 __global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __restrict__ groups, uint32_t n_groups, uint32_t gx_comb, ScFusedPack seqpack, uint32_t n_seq, uint32_t gx_seq, size_t q,
-                                                           ScScalar rmont, uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
+                                                           ScScalar rmont, uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq,
+                                                           unsigned long long* __restrict__ dbg /* null, or 4 words per block: kind, XCC id, start, end (100 MHz clock) — SBN_SC_DEBUG_BLOCKS */) {
   const unsigned long long Ts = (unsigned long long)n_seq * gx_seq, T = Ts + (unsigned long long)n_groups * gx_comb, b = blockIdx.x;
   const unsigned long long s0 = b * Ts / T, s1 = (b + 1) * Ts / T;
   const Fr r = fr_from_words(rmont);
+  const unsigned long long t_begin = dbg ? wall_clock64() : 0ull;
   if (s1 > s0) {
     const uint32_t inst = (uint32_t)(s0 % n_seq), bidx = (uint32_t)(s0 / n_seq);
     ScFusedArgs a;
@@ -167,6 +169,11 @@ __global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __
   } else {
     const uint32_t ci = (uint32_t)(b - s0), grp = ci % n_groups, bidx = ci / n_groups;
     sc_comb_bind_eval_body<SCALE>(groups + grp, q, r, partial_comb, tickets, out, n_seq + grp, seq, bidx, gx_comb);
+  }
+  if (dbg && threadIdx.x == 0) {
+    dbg[4 * b] = s1 > s0 ? 1ull : 0ull;
+    dbg[4 * b + 1] = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);      // HW_REG_XCC_ID[3:0]
+    dbg[4 * b + 2] = t_begin; dbg[4 * b + 3] = wall_clock64();
   }
 }
 
