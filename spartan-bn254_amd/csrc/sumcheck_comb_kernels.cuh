@@ -180,14 +180,11 @@ __global__ void __launch_bounds__(256, 2) k_sc_round_mixed(const ScCombGroup* __
 
 // ---- round 0 of the "par" group: the combined sums of the UNBOUND tables (no challenge yet) ---------------------------------------
 // A is scaled in registers when the tables are still unscaled (scale != 0: two products per instance), C = g->c is the table itself.
-__global__ void __launch_bounds__(256, 2) k_sc_comb_eval(const ScCombGroup* __restrict__ groups, size_t half, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
-                                                         uint32_t* __restrict__ out, uint32_t slot0, uint32_t seq) {
-  const ScCombGroup* __restrict__ g = groups + blockIdx.y;
+__device__ __forceinline__ void sc_comb_eval_body(const ScCombGroup* __restrict__ g, size_t half, Fr& e0, Fr& e2, Fr& e3, uint32_t bidx, uint32_t nblk) {
   const uint32_t n = g->n;
   const bool scale = g->scale != 0;
-  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
   uint32_t c0 = 0, c2 = 0, c3 = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)bidx * blockDim.x + threadIdx.x; i < half; i += (size_t)nblk * blockDim.x) {
     Cols LL, HH, DD; cols_zero(LL); cols_zero(HH); cols_zero(DD);
     ScQuad zn;
     zn.z0 = fe_gload<FrP>(g->a_src[0] + 8 * i); zn.z1 = fe_gload<FrP>(g->a_src[0] + 8 * (i + half));
@@ -211,8 +208,46 @@ __global__ void __launch_bounds__(256, 2) k_sc_comb_eval(const ScCombGroup* __re
     const ScPts pc = sc_points_u(cl, ch);
     fr_acc32(e0, fe_mulu(S.s0, cl), c0); fr_acc32(e2, fe_mulu(S.s2, pc.v2), c2); fr_acc32(e3, fe_mulu(S.s3, pc.v3), c3);
   }
+}
+__global__ void __launch_bounds__(256, 2) k_sc_comb_eval(const ScCombGroup* __restrict__ groups, size_t half, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
+                                                         uint32_t* __restrict__ out, uint32_t slot0, uint32_t seq) {
+  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+  sc_comb_eval_body(groups + blockIdx.y, half, e0, e2, e3, blockIdx.x, gridDim.x);
   sc_block_sums_store_at(e0, e2, e3, partial, slot0 + blockIdx.y, blockIdx.x, gridDim.x);
   sc_last_block_fold_at(partial, tickets, out, 3, seq, slot0 + blockIdx.y, gridDim.x);
+}
+
+// Round 0 of a sumcheck with both kinds of instance as ONE launch (as k_sc_round_mixed does for the binds): the "seq" instances'
+// cubic sums (the loop of k_sc_eval<KIND_CUBIC>, 6 products per index: VALU-heavy) interleaved with the "par" groups' combined sums.
+// Slots: seq instance j -> j, group g -> n_seq + g.
+__global__ void __launch_bounds__(256, 2) k_sc_eval_mixed(const ScCombGroup* __restrict__ groups, uint32_t n_groups, uint32_t gx_comb, ScArgsPack seqpack, uint32_t n_seq, uint32_t gx_seq, size_t half,
+                                                          uint32_t* __restrict__ partial_seq, uint32_t* __restrict__ partial_comb, uint32_t* __restrict__ tickets, uint32_t* __restrict__ out, uint32_t seq) {
+  const unsigned long long Ts = (unsigned long long)n_seq * gx_seq, T = Ts + (unsigned long long)n_groups * gx_comb, b = blockIdx.x;
+  const unsigned long long s0 = b * Ts / T, s1 = (b + 1) * Ts / T;
+  Fr e0 = fe_zero<FrP>(), e2 = e0, e3 = e0;
+  if (s1 > s0) {
+    const uint32_t inst = (uint32_t)(s0 % n_seq), bidx = (uint32_t)(s0 / n_seq);
+    ScArgs a;
+#pragma unroll
+    for (int i = 0; i < SC_PACK_MAX; i++) if (i == (int)inst) a = seqpack.a[i];
+    uint32_t c0 = 0, c2 = 0, c3 = 0;
+    for (size_t i = (size_t)bidx * blockDim.x + threadIdx.x; i < half; i += (size_t)gx_seq * blockDim.x) {
+      const Fr al = fe_gload<FrP>(a.t[0] + 8 * i), ah = fe_gload<FrP>(a.t[0] + 8 * (i + half));
+      const Fr bl = fe_gload<FrP>(a.t[1] + 8 * i), bh = fe_gload<FrP>(a.t[1] + 8 * (i + half));
+      const Fr cl = fe_gload<FrP>(a.t[2] + 8 * i), ch = fe_gload<FrP>(a.t[2] + 8 * (i + half));
+      const ScPts pa = sc_points_u(al, ah), pb = sc_points_u(bl, bh), pc = sc_points_u(cl, ch);
+      fr_acc(e0, fe_mulu(fe_mulu(al, bl), cl), c0);
+      fr_acc(e2, fe_mulu(fe_mulu(pa.v2, pb.v2), pc.v2), c2);
+      fr_acc(e3, fe_mulu(fe_mulu(pa.v3, pb.v3), pc.v3), c3);
+    }
+    sc_block_sums_store_at(e0, e2, e3, partial_seq, inst, bidx, gx_seq);
+    sc_last_block_fold_at(partial_seq, tickets, out, 3, seq, inst, gx_seq);
+  } else {
+    const uint32_t ci = (uint32_t)(b - s0), grp = ci % n_groups, bidx = ci / n_groups;
+    sc_comb_eval_body(groups + grp, half, e0, e2, e3, bidx, gx_comb);
+    sc_block_sums_store_at(e0, e2, e3, partial_comb, n_seq + grp, bidx, gx_comb);
+    sc_last_block_fold_at(partial_comb, tickets, out, 3, seq, n_seq + grp, gx_comb);
+  }
 }
 
 }  // namespace sbn

@@ -89,7 +89,7 @@ def check_signal(name, code, idx, what):
 def test_kernels_found(kernels):
     names = " ".join(kernels)
     for frag in ("k_sc_evalILi0", "k_sc_evalILi1", "k_sc_evalILi2", "k_sc_bind_eval_pfILi0", "k_sc_bind_eval_tinyILi0", "k_sc_bind_evalILi0ELi2", "k_sc_comb_eval", "k_sc_comb_bind_evalILb0", "k_sc_comb_bind_evalILb1",
-                 "k_sc_finals"):
+                 "k_sc_finals", "k_sc_finals_gather", "k_sc_round_mixedILb0", "k_sc_round_mixedILb1", "k_sc_eval_mixed"):
         assert frag in names, f"{frag} missing from the code object"
 
 
