@@ -150,3 +150,45 @@ struct ProfScope {
 #define LAUNCH(c, name, kern, grid, block, ...) \
   do { ProfScope _ps((c), name); hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, (c)->stream, __VA_ARGS__); } while (0)
 #define LAUNCHCHK(c) HIPCHK(c, hipGetLastError())
+
+// ---- the host mailbox (coherent pinned memory the result kernels write straight into) and its waits ----
+// ticket counters of the single-launch rounds: zero at rest (the last block resets its counter)
+static int sc_tickets(sbn_ctx* c) {
+  if (c->mbox && c->sc_tickets.cap) return SBN_OK;
+  if (!c->mbox) {                                  // the mailbox first: a failed allocation must not leave the tickets looking initialised
+    uint32_t* mb = nullptr;
+    HIPCHK(c, hipHostMalloc((void**)&mb, SC_MBOX_WORDS * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(mb, 0, SC_MBOX_WORDS * 4);
+    c->mbox = mb;
+  }
+  if (!c->sc_tickets.cap) {
+    int rc; if ((rc = ensure(c, c->sc_tickets, 4096 * 4))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->sc_tickets.p, 0, 4096 * 4, c->stream));
+  }
+  return SBN_OK;
+}
+// Wait for the `count` flags of launch `seq`: a short spin on the mailbox (the kernel is microseconds long when this path
+// matters), then the ordinary stream synchronisation.  With event profiling on, always synchronise (the events must be complete).
+static int sc_mbox_wait(sbn_ctx* c, size_t count, uint32_t seq) {
+  volatile uint32_t* fl = c->mbox + SC_MBOX_FLAGS;
+  if (!c->prof) {
+    for (int spin = 0; spin < 200000; spin++) {
+      size_t done = 0; while (done < count && fl[done] == seq) done++;
+      if (done == count) { std::atomic_thread_fence(std::memory_order_acquire); return SBN_OK; }
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  for (size_t i = 0; i < count; i++) if (fl[i] != seq) return fail(c, SBN_EHIP, "sumcheck round: result flag %zu missing after synchronisation", i);
+  return SBN_OK;
+}
+// one flag word of the mailbox (the stateful sumcheck's final claims): spin briefly, then synchronise
+static int sc_flag_wait(sbn_ctx* c, volatile uint32_t* flag, uint32_t seq) {
+  if (!c->prof) {
+    for (int spin = 0; spin < 200000; spin++) if (*flag == seq) { std::atomic_thread_fence(std::memory_order_acquire); return SBN_OK; }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->prof) prof_drain(c);
+  if (*flag != seq) return fail(c, SBN_EHIP, "result flag missing in the host mailbox after synchronisation");
+  return SBN_OK;
+}

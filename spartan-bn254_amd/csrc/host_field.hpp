@@ -62,11 +62,43 @@ static inline Fq sqr(const Fq& a) { return mul(a, a); }
 static inline Fq dbl(const Fq& a) { return add(a, a); }
 static inline Fq one() { Fq r; memcpy(r.v, QONE, 32); return r; }
 static inline Fq zero() { Fq r = {{0, 0, 0, 0}}; return r; }
-static inline Fq inv(const Fq& a) {
+static inline Fq inv_fermat(const Fq& a) {
   uint64_t e[4] = {QP[0] - 2, QP[1], QP[2], QP[3]};
   Fq acc = one();
   for (int i = 255; i >= 0; i--) { acc = sqr(acc); if ((e[i >> 6] >> (i & 63)) & 1) acc = mul(acc, a); }
   return acc;
+}
+// 1 / x of an integer 0 < x < m (m odd, below 2^255), as an integer: the binary extended Euclid — u, v shrink by shifts and
+// subtractions while b x = u and c x = v (mod m) are kept.  ~2 x 254 steps on four limbs: 2-3 us against ~15-20 us for Fermat's 380
+// Montgomery products.  Variable time: its operands are public (coordinates of commitments, transcript challenges).
+static inline void inv_mod_odd(const uint64_t x[4], const uint64_t m[4], uint64_t out[4]) {
+  auto is_one = [](const uint64_t a[4]) { return a[0] == 1 && (a[1] | a[2] | a[3]) == 0; };
+  auto shr1 = [](uint64_t a[4], uint64_t top) { a[0] = (a[0] >> 1) | (a[1] << 63); a[1] = (a[1] >> 1) | (a[2] << 63); a[2] = (a[2] >> 1) | (a[3] << 63); a[3] = (a[3] >> 1) | (top << 63); };
+  auto halve = [&](uint64_t a[4]) {                       // a / 2 mod m for a < m: (a + m) / 2 when a is odd
+    uint64_t c = 0;
+    if (a[0] & 1) for (int i = 0; i < 4; i++) { u128 s = (u128)a[i] + m[i] + c; a[i] = (uint64_t)s; c = (uint64_t)(s >> 64); }
+    shr1(a, c);
+  };
+  auto lt = [](const uint64_t a[4], const uint64_t b[4]) { for (int i = 3; i >= 0; i--) { if (a[i] < b[i]) return true; if (a[i] > b[i]) return false; } return false; };
+  auto sub_raw = [](uint64_t a[4], const uint64_t b[4]) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a[i] - b[i] - br; a[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } };
+  auto sub_mod = [&](uint64_t a[4], const uint64_t b[4]) {        // a <- a - b mod m, both below m
+    if (lt(a, b)) { uint64_t c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a[i] + m[i] + c; a[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
+    sub_raw(a, b);
+  };
+  uint64_t u[4] = {x[0], x[1], x[2], x[3]}, v[4] = {m[0], m[1], m[2], m[3]}, b[4] = {1, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+  while (!is_one(u) && !is_one(v)) {
+    while (!(u[0] & 1)) { shr1(u, 0); halve(b); }
+    while (!(v[0] & 1)) { shr1(v, 0); halve(c); }
+    if (lt(v, u)) { sub_raw(u, v); sub_mod(b, c); } else { sub_raw(v, u); sub_mod(c, b); }
+  }
+  memcpy(out, is_one(u) ? b : c, 32);
+}
+// Montgomery form in, Montgomery form out: the integer inverse of a R is a^-1 R^-1; two products with R^2 bring it to a^-1 R.  0 -> 0.
+static inline Fq inv(const Fq& a) {
+  if (is_zero(a)) return a;
+  Fq x, r2; memcpy(r2.v, QR2, 32);
+  inv_mod_odd(a.v, QP, x.v);
+  return mul(mul(x, r2), r2);
 }
 static inline Fq from_mont(const Fq& a) { Fq o = {{1, 0, 0, 0}}; return mul(a, o); }
 static inline Fq to_mont(const Fq& a) { Fq r2; memcpy(r2.v, QR2, 32); return mul(a, r2); }
@@ -172,9 +204,8 @@ static inline El mmul(const El& a, const El& b) {
 static inline El to_m(const El& a) { El r2; memcpy(r2.v, R2, 32); return mmul(a, r2); }                 // a * 2^256
 static inline El from_m(const El& a) { return mmul(a, from_u64(1)); }
 static inline bool is_zero(const El& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
-// 1 / a for a != 0, canonical in and out: the binary extended Euclid on 4 limbs (u, v shrink by shifts and subtractions while
-// b * a = u and c * a = v mod r are kept; ~2 x 254 steps, 2-3 us against ~20 us for Fermat's 380 Montgomery products).  Variable
-// time: the operands here are transcript challenges and batching coefficients, public values.  0 has no inverse: returns 0.
+// 1 / a, canonical in and out: Fermat's exponentiation (kept as the cross-check of the tests) and the binary Euclid above
+// (inv_mod_odd; the operands here are transcript challenges and batching coefficients, public values).  0 has no inverse: returns 0.
 static inline El inv_fermat(const El& a) {
   const uint64_t e[4] = {P[0] - 2, P[1], P[2], P[3]};
   const El am = to_m(a);
@@ -184,23 +215,8 @@ static inline El inv_fermat(const El& a) {
 }
 static inline El inv(const El& a) {
   if (is_zero(a)) return a;
-  auto is_one = [](const uint64_t x[4]) { return x[0] == 1 && (x[1] | x[2] | x[3]) == 0; };
-  auto shr1 = [](uint64_t x[4], uint64_t top) { x[0] = (x[0] >> 1) | (x[1] << 63); x[1] = (x[1] >> 1) | (x[2] << 63); x[2] = (x[2] >> 1) | (x[3] << 63); x[3] = (x[3] >> 1) | (top << 63); };
-  auto halve = [&](uint64_t x[4]) {                       // x / 2 mod r for x < r: (x + r) / 2 when x is odd (x + r < 2^255)
-    uint64_t c = 0;
-    if (x[0] & 1) { for (int i = 0; i < 4; i++) { u128 s = (u128)x[i] + P[i] + c; x[i] = (uint64_t)s; c = (uint64_t)(s >> 64); } }
-    shr1(x, c);
-  };
-  auto lt = [](const uint64_t x[4], const uint64_t y[4]) { for (int i = 3; i >= 0; i--) { if (x[i] < y[i]) return true; if (x[i] > y[i]) return false; } return false; };
-  auto sub_raw = [](uint64_t x[4], const uint64_t y[4]) { uint64_t br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)x[i] - y[i] - br; x[i] = (uint64_t)d; br = (uint64_t)(d >> 127); } };
-  uint64_t u[4] = {a.v[0], a.v[1], a.v[2], a.v[3]}, v[4] = {P[0], P[1], P[2], P[3]};
-  El b = from_u64(1), c = from_u64(0);
-  while (!is_one(u) && !is_one(v)) {
-    while (!(u[0] & 1)) { shr1(u, 0); halve(b.v); }
-    while (!(v[0] & 1)) { shr1(v, 0); halve(c.v); }
-    if (lt(v, u)) { sub_raw(u, v); b = sub(b, c); } else { sub_raw(v, u); c = sub(c, b); }
-  }
-  return is_one(u) ? b : c;
+  El r; inv_mod_odd(a.v, P, r.v);
+  return r;
 }
 // canonical x -> the device's table representation x * 2^261 mod r (fp.cuh's Montgomery domain), canonical
 static inline El to_dev_mont(const El& x) {

@@ -443,14 +443,19 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   if ((rc = input_check_begin(c))) return rc;
   if (L <= 16) {
     // a handful of rows: the per-row Fermat inversion is a ~0.3 ms single-lane chain on the device and ~15 us on a host core
-    if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 128)))) return rc;
+    // the sums and the input-check counter go straight into the host mailbox, flag behind them (the sumcheck rounds' protocol):
+    // one small launch and a poll instead of two copies and a stream synchronisation — a bullet round commits 2 rows at a time
+    if ((rc = sc_tickets(c))) return rc;
     if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, nullptr, nullptr))) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->pin, c->wsum.p, L * 128, hipMemcpyDeviceToHost, c->stream));
-    if ((rc = input_check_fetch(c))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->prof) prof_drain(c);
+    const uint32_t seq = ++c->mbox_seq;
+    uint32_t* hfin = c->mbox + SC_MBOX_FINALS;
+    static_assert(16 * 32 + 1 <= SC_MBOX_WORDS - SC_MBOX_FINALS, "mailbox: 16 XYZZ sums + the counter must fit the final-claims area");
+    LAUNCH(c, "k_points_to_host", k_sc_finals_raw, 1, 256, (const uint32_t*)c->wsum.p, (uint32_t)(L * 32), (const uint32_t*)c->d_bad, hfin, c->mbox + SC_MBOX_FLAGS + SC_PACK_MAX, seq);
+    LAUNCHCHK(c);
+    if ((rc = sc_flag_wait(c, c->mbox + SC_MBOX_FLAGS + SC_PACK_MAX, seq))) return rc;
+    *c->h_bad = hfin[L * 32];
     if ((rc = input_check_end(c))) return rc;
-    const sbn_host::Pt* S = (const sbn_host::Pt*)c->pin;
+    sbn_host::Pt S[16]; memcpy(S, hfin, L * 128);
     for (size_t i = 0; i < L; i++) { int inf = 0; sbn_host::to_affine_bytes(sbn_host::pt_from_device(S[i]), out_xy + 64 * i, &inf); if (out_inf) out_inf[i] = (uint8_t)inf; }
     return SBN_OK;
   }

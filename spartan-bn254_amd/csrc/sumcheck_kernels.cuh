@@ -713,4 +713,24 @@ __global__ void __launch_bounds__(256) k_gather_merge(const GatherArgs* __restri
 }
 __global__ void k_fr_set_one(uint32_t* out) { if (threadIdx.x == 0 && blockIdx.x == 0) fe_store_packed<FrP>(out, fe_one<FrP>()); }
 
+// the final claims (sumcheck.rs:302-318): fin[t] (the single entry the last bind left of table t, Montgomery form) as canonical integers
+// straight into the host mailbox, flag behind them — no copy, no stream synchronisation (the protocol of the round kernels)
+__global__ void __launch_bounds__(128) k_sc_finals(const uint32_t* __restrict__ fin, size_t count, uint32_t* __restrict__ host_out, uint32_t* __restrict__ flag, uint32_t seq) {
+  const size_t t = threadIdx.x;
+  if (t < count) fe_store_packed<FrP>(host_out + 8 * t, fe_from_mont(fe_load<FrP>(fin + 8 * t)));
+  sc_drain_stores();
+  __syncthreads();
+  if (t == 0) sc_flag_store(flag, seq);
+}
+
+// raw words (the XYZZ sums of a few row commitments) and one extra word (the input-check counter) to the host mailbox, flag behind them:
+// a 2-row commitment of a bullet round then costs one 4 us launch and a poll instead of two copies and a stream synchronisation
+__global__ void __launch_bounds__(256) k_sc_finals_raw(const uint32_t* __restrict__ src, uint32_t nwords, const uint32_t* __restrict__ extra, uint32_t* __restrict__ host_out, uint32_t* __restrict__ flag, uint32_t seq) {
+  for (uint32_t t = threadIdx.x; t < nwords; t += 256) host_out[t] = src[t];
+  if (threadIdx.x == 0 && extra) host_out[nwords] = *extra;
+  sc_drain_stores();
+  __syncthreads();
+  if (threadIdx.x == 0) sc_flag_store(flag, seq);
+}
+
 }  // namespace sbn

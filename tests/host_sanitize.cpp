@@ -16,6 +16,8 @@ int main() {
   // field identities
   Fq a = to_mont(Fq{{123456789, 987654321, 5, 7}}), b = to_mont(Fq{{42, 0, 0, 1}});
   if (!eq(mul(a, inv(a)), one())) { printf("inv\n"); bad++; }
+  { Fq x = a; for (int i = 0; i < 100; i++) { x = add(sqr(x), b); if (!eq(inv(x), inv_fermat(x)) || !eq(mul(x, inv(x)), one())) { printf("inv vs fermat\n"); bad++; break; } }
+    Fq pm1 = sub(zero(), one()); if (!eq(inv(pm1), inv_fermat(pm1)) || !eq(inv(one()), one()) || !is_zero(inv(zero()))) { printf("inv edge\n"); bad++; } }
   if (!eq(sub(add(a, b), b), a)) { printf("addsub\n"); bad++; }
   if (!eq(from_mont(to_mont(Fq{{9, 8, 7, 6}})), Fq{{9, 8, 7, 6}})) { printf("mont\n"); bad++; }
   // scalar field: the binary-Euclid inverse against Fermat's, and a * 1/a = 1, on edge values and a pseudo-random walk
