@@ -18,7 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = sbn.Context(0)
 t_end = time.time() + budget
-counts = {"msm": 0, "commit": 0, "sumcheck": 0, "bullet": 0}
+counts = {"msm": 0, "commit": 0, "sumcheck": 0, "stateful": 0, "bullet": 0}
 
 
 def special(b, n):
@@ -33,7 +33,7 @@ def special(b, n):
 case = 0
 while time.time() < t_end:
     case += 1
-    kind = rng.choice(["msm", "commit", "commit", "sumcheck", "bullet"])
+    kind = rng.choice(["msm", "commit", "commit", "sumcheck", "stateful", "stateful", "bullet"])
     sd = rng.randrange(1 << 30)
     if kind == "msm":
         n = rng.choice([1, 2, 3, 31, 64, 257, 1000, 4097, 20000, 70000, 150000])
@@ -80,6 +80,34 @@ while time.time() < t_end:
                 if len(dev[0]) < 2: break
                 ev = ctx.sc_eval_cubic_batched(As, Bs, Cs)
         assert [ctx.table_read0(t) for t in dev] == host, ("sumcheck final", logn, cnt, sd)
+        for t in dev: t.free()
+    elif kind == "stateful":
+        # sbn_sumcheck_begin / round / finish against the oracle's whole prove_cubic_batched loop: every round's combined triple and
+        # the final claims; random instance counts, sizes on both sides of the combined kernels' threshold, edge coefficients
+        logn = rng.choice([1, 2, 4, 7, 10, 13, 15, 16, 17]); n = 1 << logn
+        n_par = rng.choice([0, 1, 2, 5, 12, 17]); n_seq = rng.choice([0, 0, 1, 3, 6])
+        if n_par + n_seq == 0: n_par = 1
+        if n_par + n_seq > 24: n_seq = 24 - n_par
+        ntab = 2 * n_par + (1 if n_par else 0) + 3 * n_seq
+        host = [rand_scalars(n, sd + i) for i in range(ntab)]
+        dev = [ctx.table_upload(x) for x in host]
+        o = 2 * n_par + (1 if n_par else 0)
+        co = bytearray(rand_scalars(n_par + n_seq, sd + 100))
+        for _ in range(rng.choice([0, 0, 1, 2])):
+            i = rng.randrange(n_par + n_seq); co[32 * i:32 * i + 32] = pr.scalar_to_bytes(rng.choice([0, 1, 2, pr.R - 1]))
+        co = bytes(co); ch = rand_scalars(logn, sd + 101)
+        st, ev = ctx.sumcheck_begin(dev[:n_par], dev[n_par:2 * n_par], dev[2 * n_par] if n_par else None, dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:], co)
+        got = [ev]
+        for j in range(logn):
+            ev = st.round(ch[32 * j:32 * j + 32])
+            if j + 1 < logn: got.append(ev)
+        fin = st.finish(); st.free()
+        import numpy as np
+        hn = [np.frombuffer(x, dtype=np.uint8) for x in host]
+        _, want_comb, want_fin = ol.sc_prove_cubic_batched(hn[:n_par], hn[n_par:2 * n_par], hn[2 * n_par] if n_par else None, hn[o:o + n_seq], hn[o + n_seq:o + 2 * n_seq], hn[o + 2 * n_seq:], co, ch, 8)
+        assert got == list(want_comb[:logn]), ("stateful rounds", logn, n_par, n_seq, sd)
+        assert fin == want_fin, ("stateful finals", logn, n_par, n_seq, sd)
+        assert ctx.table_read0_many(dev) == [x[:32] for x in host], ("stateful left the caller's tables alone", sd)
         for t in dev: t.free()
     else:
         lg = rng.randrange(1, 8); n = 1 << lg
