@@ -653,13 +653,13 @@ def _run_stateful_sumcheck(ctx, ol, n, n_par, n_seq, seed, coeffs=None, threads=
 
 @pytest.mark.parametrize("logn,n_par,n_seq", [(1, 1, 0), (1, 3, 2), (2, 2, 1), (3, 12, 6), (6, 1, 1), (9, 4, 0), (10, 12, 6), (10, 0, 3), (12, 18, 6), (14, 5, 2)])
 def test_stateful_sumcheck_small(ctx, ol, logn, n_par, n_seq):
-    """tables below 2^15 entries: the "par" A tables are scaled by coeffs when the sumcheck begins, per-instance kernels after that"""
+    """small tables (below 2^16 entries the "par" A tables are scaled by coeffs when the sumcheck begins, per-instance kernels after that)"""
     _run_stateful_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 7000 + 10 * logn + n_par)
 
 
 @pytest.mark.parametrize("logn,n_par,n_seq", [(15, 2, 0), (15, 12, 6), (16, 4, 0), (16, 13, 3), (17, 16, 0), (17, 20, 4), (18, 7, 1), (19, 12, 0)])
 def test_stateful_sumcheck_combined_kernels(ctx, ol, logn, n_par, n_seq):
-    """tables of 2^15 entries and more: the combined kernels (coefficients folded into A at the first bind, one reduction per index for
+    """2^15 (still the scaled per-instance path) and from 2^16 entries the combined kernels (coefficients folded into A at the first bind, one reduction per index for
     all instances, several groups when the round is small or the instances many), then the per-instance kernels on the scaled tables"""
     _run_stateful_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 7500 + 10 * logn + n_par)
 
