@@ -132,6 +132,53 @@ def stored_traffic(workload, size_key, kernel):
     return None
 
 
+def summarize(line):
+    """the round's figures in one compact object (<= ~1.5 kB), emitted as the LAST key of the JSON line so that it survives a stored tail"""
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    s = {"msm_2^20": {"points_per_s": line.get("value"), "ms_per_step": line.get("ms_per_step"), "one_msm_alone_ms": g(line, "serial_reference", "ms_per_step"),
+                      "k_acc_first_ms": g(line, "roofline", "kernel_avg_ms"), "hbm_frac": g(line, "roofline", "frac"), "alu_frac": g(line, "roofline", "alu", "frac"),
+                      "traffic_bytes": g(line, "roofline", "traffic")}}
+    hy = line.get("hyrax")
+    if isinstance(hy, dict):
+        h = {k: g(hy, k, "ms_per_step") for k in ("lookup", "bucket") if isinstance(hy.get(k), dict)}
+        for k in ("lookup", "bucket"):
+            if g(hy, k, "roofline", "frac") is not None:
+                h[k + "_hbm_frac"] = g(hy, k, "roofline", "frac")
+        if g(hy, "lookup", "lookup_table", "window_bits"):
+            h["lookup_window_bits"] = g(hy, "lookup", "lookup_table", "window_bits")
+        for k, v in (hy.get("variants") or {}).items():
+            h[k] = v.get("ms_per_step")
+        if "error" in hy:
+            h["error"] = hy["error"][:80]
+        s["hyrax_ms"] = h
+    sw = line.get("msm_sweep")
+    if isinstance(sw, dict):
+        s["msm_sweep"] = {k: {"ms": v.get("ms_per_step"), "points_per_s": v.get("points_per_s"), "alu_frac": g(v, "roofline", "alu", "frac")} for k, v in sw.items() if isinstance(v, dict)}
+    sc = line.get("sumcheck")
+    if isinstance(sc, dict):
+        s["sumcheck"] = {"stateful_ms": g(sc, "stateful", "ms_per_sumcheck"), "fused_ms": g(sc, "fused", "ms_per_sumcheck"), "hbm_frac": g(sc, "roofline", "frac"),
+                         "first_launch_frac": g(sc, "roofline", "largest_launch", "frac"), "round0_ms": g(sc, "stateful", "kernels_ms_total", "k_sc_eval_mixed"),
+                         "traffic_bytes": g(sc, "roofline", "traffic")}
+    ps = line.get("prove_stages")
+    if isinstance(ps, dict):
+        s["prove"] = {"total_device_side_ms": ps.get("total_device_side_ms"), "stage_ms": {x["stage"]: x["ms"] for x in ps.get("stages", [])},
+                      "detail_ms": ps.get("detail_ms"), "digest": ps.get("transcript_digest")}
+        if "error" in ps:
+            s["prove"] = {"error": ps["error"][:80]}
+    gr = line.get("group")
+    if isinstance(gr, dict):
+        s["group"] = {k: (v.get("ms_per_commit") or v.get("ms_per_commit_incl_pcie") or v.get("ms_per_msm")) for k, v in gr.items() if isinstance(v, dict)}
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        s["cpu_points_per_s"] = {"cores_%d" % cb.get("cores", 0): cb.get("value"), "cores_1": g(cb, "one_thread", "value")}
+    return s
+
+
 class Timer:
     def __init__(self, barrier):
         self.barrier = barrier
@@ -165,6 +212,9 @@ def main():
     ap.add_argument("--group-devices", default="", help="comma list of device indices (repeats allowed): adds a `group` block — ONE Hyrax matrix and ONE 2^26 MSM over "
                     "those devices from THIS process through the C ABI's device groups (sbn_group_*: host threads per device, no launcher, no collective); needs --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="world size 1 only: still initialise the process group (backend nccl = RCCL, device_id = this GPU) and send every "
+                    "partial sum / row commitment through the same all-gathers the N > 1 run uses (sharding.allgather_fold / gather_rows on device uint8 tensors) — "
+                    "the collective code path exercised on a one-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,8 +238,10 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    use_coll = world > 1 or args.force_collective          # partial sums / row commitments travel through torch.distributed
+    if use_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + (os.getpid() % 2000)))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -204,14 +256,14 @@ def main():
     blocks = set() if args.blocks == "none" else ({"hyrax", "sweep", "sumcheck", "prove_stages"} if args.blocks == "all" else set(args.blocks.split(",")))
 
     def barrier():
-        if world > 1:
+        if use_coll:
             dist.barrier()
         torch.cuda.synchronize()
         for cx in ctxs:
             cx.sync()
 
     def max_over_ranks(dt):
-        if world == 1:
+        if not use_coll:
             return dt
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -226,13 +278,12 @@ def main():
 
     def fold_partials(parts):
         """one all-gather for the partial sums of the steps that just completed, then the local folds"""
-        if world == 1:
+        if not use_coll:
             return parts
+        if len(parts) == 1:
+            return [sharding.allgather_fold(parts[0][0], device=coll_dev)]
         xy, _ = zip(*parts)
-        t = torch.frombuffer(bytearray(b"".join(xy)), dtype=torch.uint8).to(coll_dev)
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        allb = [o.cpu().numpy().tobytes() for o in outs]
+        allb = sharding.allgather_bytes(b"".join(xy), device=coll_dev)
         return [sbn.g1_sum(b"".join(a[64 * j:64 * j + 64] for a in allb)) for j in range(len(parts))]
 
     # ------------------------------------------------------------------------------------------------ one MSM problem
@@ -245,7 +296,7 @@ def main():
 
     def check_sharded(total, want):
         """the folded result must be the sum of all ranks' expectations"""
-        if world == 1:
+        if not use_coll:
             return total == want
         wants = [None] * world
         dist.all_gather_object(wants, want)
@@ -265,7 +316,7 @@ def main():
                 for _ in range(count):
                     fold_partials([local(cx_list[0])])
                 return
-            if world == 1:
+            if not use_coll:
                 shares = [count // Mx + (1 if j < count % Mx else 0) for j in range(Mx)]
                 futs = [pool.submit(lambda cx=cx, k=k: [local(cx) for _ in range(k)]) for cx, k in zip(cx_list, shares)]
                 for f in futs:
@@ -355,7 +406,7 @@ def main():
             roofline["alu"] = msm_alu(ctx.prof_last_job(), dom_ms)
         workload = f"synthetic BN254 G1 MSM, 2^{args.log_n} uniform Fr scalars x distinct bases per GPU, inputs resident in HBM"
         sharding_desc = "base-point ranges + one RCCL all-gather of 64-B partial sums"
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if rank == 0 and not args.no_cpu_baseline:          # rank 0 only, at every N (the other ranks wait at the next barrier, outside any timed region)
             cores = min(len(os.sched_getaffinity(0)), 16)
             ns = min(n, 1 << 20); n1 = min(n, 1 << 18)
             pts = ctx.bases_download(bases, 0, ns)
@@ -385,7 +436,7 @@ def main():
 
         def hy_step():
             out, _ = ctx.commit_rows_dev(bases, Zl.data_ptr(), 0, nl, Rc)
-            return sharding.gather_rows(out, L, rank, world, device=coll_dev) if world > 1 else out
+            return sharding.gather_rows(out, L, rank, world, device=coll_dev) if use_coll else out
 
         out = hy_step()
         gxy, _ = ol.gens_new(Rc, b"gens_r1cs_eval")
@@ -401,7 +452,7 @@ def main():
         units_per_step = L * Rc / world
         dominant = "k_comb_rows" if comb_c else "k_acc_first"
         alg = nl * Rc * 32.0 + (Rc + 1) * 64.0 + nl * 64.0
-        roofline = hbm_roofline(alg, dominant, serial["kernels_avg_ms"].get(dominant, 0.0), stored_traffic("hyrax-lookup" if comb_c else "hyrax-bucket", f"{L}x{Rc}", dominant) if world == 1 else None)
+        roofline = hbm_roofline(alg, dominant, serial["kernels_avg_ms"].get(dominant, 0.0), stored_traffic("hyrax-lookup" if comb_c else "hyrax-bucket", f"{nl}x{Rc}", dominant))
         workload = f"Hyrax derefs commitment: ONE {L} x {Rc} matrix of uniform Fr scalars, {Rc}+1 shared reference generators, last quarter of rows zero, inputs resident in HBM" + (
             f", fixed-base lookup table c={comb_c}" if comb_c else ", bucket method")
         sharding_desc = "interleaved rows of one matrix per rank, joined by one all-gather of the row commitments; no data-path reduction"
@@ -426,7 +477,7 @@ def main():
 
             def hy_step():
                 out, _ = ctx.commit_rows_dev(hb, Zl.data_ptr(), 0, nl, Rc)
-                return sharding.gather_rows(out, L, rank, world, device=coll_dev) if world > 1 else out
+                return sharding.gather_rows(out, L, rank, world, device=coll_dev) if use_coll else out
 
             variants = [("bucket", 0.0)] + ([("lookup", args.precompute_gb)] if args.precompute_gb > 0 else [])
             for name, gb in variants:                      # bucket first: the lookup table stays attached to the handle once built
@@ -438,7 +489,7 @@ def main():
                         comb_c = ctx.bases_precompute(hb, int(gb * (1 << 30)))
                     except sbn.SbnError as e:
                         err = str(e)
-                    if world > 1:                          # the variant's steps hold a collective: every rank runs it or none does
+                    if use_coll:                           # the variant's steps hold a collective: every rank runs it or none does
                         flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=coll_dev)
                         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
                         if int(flag.item()) and err is None:
@@ -460,7 +511,7 @@ def main():
                 job = ctx.prof_last_job()
                 r = {"ms_per_step": round(hdt / ksteps * 1e3, 4), "pairs_per_s": round(L * Rc * ksteps / hdt, 1), "steps": ksteps, "window_bits": job["c"],
                      "parity": "6 sampled rows (first, zero-padding, last non-zero) bit-exact vs the CPU oracle",
-                     "roofline": hbm_roofline(alg, dom, hp.get(dom, 0.0), stored_traffic("hyrax-" + name, f"{L}x{Rc}", dom) if world == 1 else None),
+                     "roofline": hbm_roofline(alg, dom, hp.get(dom, 0.0), stored_traffic("hyrax-" + name, f"{nl}x{Rc}", dom)),
                      "kernels_avg_ms": hp}
                 if hp.get(dom):
                     madds = 0.75 * job["slots"] * (1.0 - args.const_tail)          # zero rows add nothing
@@ -560,7 +611,13 @@ def main():
                 raise SystemExit("strong-scaling MSM: folded result differs from the folded oracle partials")
             ksteps = 4
             sdt, sp = timed_msm([ctx], ds, bs, nn, ksteps, 1)
-            sweep[f"2^{args.strong_log_n}_strong"] = {"total_points": ntot, "points_per_rank": nn, "n_gpus": world, "scaling": "strong", "ms_per_step": round(sdt / ksteps * 1e3, 4),
+            ka = kernel_avgs(sp)
+            size_key = f"2^{nn.bit_length() - 1}" if nn & (nn - 1) == 0 else str(nn)
+            strong_roof = hbm_roofline(96.0 * nn, "k_acc_first", ka.get("k_acc_first", 0.0), stored_traffic("msm", size_key, "k_acc_first"),
+                                       {"note": "rank 0's share of the fixed-size MSM; traffic only where a stored --pmc pass of exactly this share size exists"})
+            if ka.get("k_acc_first"):
+                strong_roof["alu"] = msm_alu(ctx.prof_last_job(), ka["k_acc_first"])
+            sweep[f"2^{args.strong_log_n}_strong"] = {"roofline": strong_roof,"total_points": ntot, "points_per_rank": nn, "n_gpus": world, "scaling": "strong", "ms_per_step": round(sdt / ksteps * 1e3, 4),
                                                       "points_per_s": round(ntot * ksteps / sdt, 1), "steps": ksteps, "parity": "each partial and the folded sum bit-exact vs the discrete-log identity",
                                                       "collective": f"one all-gather of {world} x 64 B per MSM ({backend})", "kernels_avg_ms": kernel_avgs(sp)}
             bs.free(); del ds
@@ -592,14 +649,15 @@ def main():
         line = {"metric": "msm_points_per_s", "value": round(value, 1), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "u32", "data": "synthetic",
-                "config": {"workload": workload, "units_per_step_per_gpu": int(units_per_step), "steps_in_flight": M, "collective_backend": backend if world > 1 else None,
+                "config": {"workload": workload, "units_per_step_per_gpu": int(units_per_step), "steps_in_flight": M, "collective_backend": backend if use_coll else None,
                            "sharding": sharding_desc, "parity": "bit-exact vs the discrete-log identity / CPU oracle, checked before timing"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kernel_avgs(prof), "serial_reference": serial}
         line.update(line_extra)
+        line["summary"] = summarize(line)          # LAST key: the driver keeps only the tail of a long line
         print(json.dumps(line), flush=True)
     for cx in ctxs:
         cx.close()
-    if world > 1:
+    if use_coll:
         dist.destroy_process_group()
 
 
@@ -824,7 +882,7 @@ def prove_stages_block(ctx, sbn, lookup_bytes):
                         "uniform Fr; SHA3 chain in place of the Merlin transcript; fastest of three proves on one setup (generator sets, window / lookup tables, address arrays: per-circuit setup, outside the timed stages)",
             "driver": "compiled C++ caller of the C ABI (libsbn_prove_harness.so), one ABI call per sumcheck round",
             "stages": [{"stage": names[k], "ms": st["stage_ms"][k], "reference_published_s_M2Max_1thread": pub[k]} for k in binding.HARNESS_STAGES[:6]],
-            "total_device_side_ms": st["total_device_side_ms"], "reference_published_total_prove_s": 208.8,
+            "total_device_side_ms": st["total_device_side_ms"], "transcript_digest": st["transcript_digest"], "reference_published_total_prove_s": 208.8,
             "detail_ms": st["detail_ms"], "rounds": st["rounds"], "per_instance_sumcheck_calls": out["per_instance_sumcheck"],
             "not_included": "host-side Rust control flow: Instance evaluations (sparse, keyless_benchmark.rs:185-188), SpMV Az/Bz/Cz, the Sigma-protocol steps of the ZK sumchecks "
                             "(3-5 point commitments per round), Merlin hashing — they stay in Rust; the published figures include them",

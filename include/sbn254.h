@@ -242,6 +242,11 @@ int sbn_table_halves(sbn_ctx* ctx, const sbn_table* t, sbn_table** left, sbn_tab
  * The result is a table (the `comb` polynomial), ready for sbn_commit_table — the 1 GiB scalar matrix of the keyless
  * derefs commitment never crosses PCIe. */
 int sbn_gather_merge(sbn_ctx* ctx, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n, sbn_table** out);
+/* One device's share of the same polynomial when its L x R view (R a power of two, hyrax.rs:371-373) is committed by interleaved rows over
+ * several devices: only the rows row0, row0 + rstep, ... (nrows of them) are gathered, as one table of nrows x R entries for
+ * sbn_commit_table(…, L = nrows, R).  row0 = 0, rstep = 1, nrows = L gives sbn_gather_merge's table. */
+int sbn_gather_merge_rows(sbn_ctx* ctx, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n, size_t R,
+                          size_t row0, size_t rstep, size_t nrows, sbn_table** out);
 /* DensePolynomial::commit (hyrax.rs:283-308) of a device-resident table viewed as L x R (L*R == len, R == gens n); blinds as
  * in sbn_commit_rows (host pointer or NULL) */
 int sbn_commit_table(sbn_ctx* ctx, const sbn_bases* b, const sbn_table* t, const uint8_t* blinds, size_t L, size_t R,
@@ -250,7 +255,7 @@ int sbn_commit_table(sbn_ctx* ctx, const sbn_bases* b, const sbn_table* t, const
 /* ---- device groups: ONE host process, several GPUs behind one call ----
  * The reference parallelises inside one process (rayon over the rows of the Hyrax matrix, hyrax.rs:259-261; arkworks over the windows of
  * an MSM), so its drop-in has one process too: a group owns one context per listed device (a device may be listed more than once) and
- * runs every call with one host thread per device.  Nothing here needs a launcher or a collective library.
+ * runs every call with one (persistent) host thread per device.  Nothing here needs a launcher or a collective library.
  *   rows of ONE matrix: row i on device i mod N, no exchange (rows are independent);
  *   ONE MSM: contiguous base-point ranges, the N 64-byte partial sums folded on the host with sbn_g1_sum (group.rs:199-262). */
 typedef struct sbn_group sbn_group;
@@ -268,6 +273,16 @@ void sbn_group_bases_free(sbn_group* g, sbn_group_bases* gb);
 /* DensePolynomial::commit -> commit_inner (hyrax.rs:253-267) of ONE L x R matrix (host pointer) over the group; arguments as sbn_commit_rows */
 int sbn_group_commit_rows(sbn_group* g, const sbn_group_bases* gb, const uint8_t* Z, const uint8_t* blinds, size_t L, size_t R,
                           uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
+/* The same with the matrix already ON the devices: Z_dev[d] = device pointer on device d to ITS rows (d, d + N, d + 2N, ... in this order,
+ * contiguous, R x 32 B each); blinds_dev[d] likewise (32 B per row) or blinds_dev == NULL.  Only the L x 64 B of results cross PCIe. */
+int sbn_group_commit_rows_dev(sbn_group* g, const sbn_group_bases* gb, const void* const* Z_dev, const void* const* blinds_dev, size_t L, size_t R,
+                              uint32_t flags, uint8_t* out_xy, uint8_t* out_inf);
+/* Derefs::commit (sparse_mlpoly_full.rs:301-304) over the group from device-resident inputs: deref_mem + merge (sparse_mlpoly_full.rs:245-257,
+ * 293-297) and commit_inner (hyrax.rs:253-267) in one call.  mem[d * count + k] / addr_dev[d * count + k]: table k (the eq(rx) / eq(ry) tables,
+ * built per device with sbn_eq_evals on sbn_group_ctx(g, d)) and its n uint32 cell addresses ON device d.  Device d gathers and commits only
+ * the rows d, d + N, ... of the L x R view of the merged polynomial (L * R = next power of two of count * n); no blinds. */
+int sbn_group_gather_commit(sbn_group* g, const sbn_group_bases* gb, const sbn_table* const* mem, const void* const* addr_dev, size_t count, size_t n,
+                            size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf);
 /* GroupElement::msm_affine (group.rs:171-175) of ONE MSM over the group: device d takes the pairs [d n / N, (d+1) n / N) */
 int sbn_group_msm(sbn_group* g, const uint8_t* scalars, const uint8_t* points, size_t n, uint32_t flags, uint8_t out_xy[64], int* out_is_inf);
 /* the same with resident points: cut once into the per-device ranges (no h), then only scalars travel */

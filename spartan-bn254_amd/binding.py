@@ -17,8 +17,8 @@ EXPORTED_SYMBOLS = [
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
     "sbn_sumcheck_begin", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
-    "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_commit_rows_dev", "sbn_group_gather_commit", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -288,6 +288,23 @@ class Group:
         self._chk(lib().sbn_group_commit_rows(self.h, gb.h, _ptr(Z), _ptr(blinds), C.c_size_t(L), C.c_size_t(R), C.c_uint32(flags), out, inf), "sbn_group_commit_rows")
         return bytes(out), bytes(inf)
 
+    def commit_rows_dev(self, gb, z_ptrs, blind_ptrs, L, R, flags=0):
+        """z_ptrs[d]: device pointer on device d to its interleaved rows (d, d + N, ...), blind_ptrs likewise or None"""
+        N = len(self)
+        za = (C.c_void_p * N)(*z_ptrs); ba = (C.c_void_p * N)(*blind_ptrs) if blind_ptrs is not None else None
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_group_commit_rows_dev(self.h, gb.h, za, ba, C.c_size_t(L), C.c_size_t(R), C.c_uint32(flags), out, inf), "sbn_group_commit_rows_dev")
+        return bytes(out), bytes(inf)
+
+    def gather_commit(self, gb, mem, addr_ptrs, n, L, R):
+        """mem[d][k]: Table on device d, addr_ptrs[d][k]: device pointer to its n uint32 addresses -> (L x 64 B, L flags)"""
+        N = len(self); count = len(mem[0])
+        ma = (C.c_void_p * (N * count))(*[t.h for row in mem for t in row])
+        aa = (C.c_void_p * (N * count))(*[a for row in addr_ptrs for a in row])
+        out = (C.c_uint8 * (64 * L))(); inf = (C.c_uint8 * L)()
+        self._chk(lib().sbn_group_gather_commit(self.h, gb.h, ma, aa, C.c_size_t(count), C.c_size_t(n), C.c_size_t(L), C.c_size_t(R), out, inf), "sbn_group_gather_commit")
+        return bytes(out), bytes(inf)
+
     def msm(self, scalars, points, flags=0):
         out = (C.c_uint8 * 64)(); inf = C.c_int()
         self._chk(lib().sbn_group_msm(self.h, _ptr(scalars), _ptr(points), C.c_size_t(len(scalars) // 32), C.c_uint32(flags), out, C.byref(inf)), "sbn_group_msm")
@@ -542,6 +559,13 @@ class Context:
         ma = (C.c_void_p * k)(*[t.h for t in mems]); aa = (C.c_void_p * k)(*addr_dev_ptrs)
         ht = C.c_void_p()
         self._chk(lib().sbn_gather_merge(self.h, ma, aa, C.c_size_t(k), C.c_size_t(n), C.byref(ht)), "sbn_gather_merge")
+        return Table(self, ht)
+
+    def gather_merge_rows(self, mems, addr_dev_ptrs, n, R, row0, rstep, nrows):
+        k = len(mems)
+        ma = (C.c_void_p * k)(*[t.h for t in mems]); aa = (C.c_void_p * k)(*addr_dev_ptrs)
+        ht = C.c_void_p()
+        self._chk(lib().sbn_gather_merge_rows(self.h, ma, aa, C.c_size_t(k), C.c_size_t(n), C.c_size_t(R), C.c_size_t(row0), C.c_size_t(rstep), C.c_size_t(nrows), C.byref(ht)), "sbn_gather_merge_rows")
         return Table(self, ht)
 
     def commit_table(self, bases, t, blinds, L, R):

@@ -697,13 +697,17 @@ __global__ void __launch_bounds__(256) k_bound_fold(const uint32_t* __restrict__
   fe_store_tab<FrP>(out + 8 * col, fe_reduce(s));
 }
 
-// out[k*n + i] = mem[k][addr[k][i]]  (AddrTimestamps::deref_mem, sparse_mlpoly_full.rs:245-252), zero padding past count*n
+// out[k*n + i] = mem[k][addr[k][i]]  (AddrTimestamps::deref_mem, sparse_mlpoly_full.rs:245-252), zero padding past count*n.
+// With rshift >= 0 only a share of the L x R view (R = 2^rshift) is produced: local row j = row (row0 + j * rstep) of the matrix — the rows
+// one device commits when the derefs matrix is dealt over a device group by interleaved rows (out then holds `padded` = nrows * R entries).
 struct GatherArgs { const uint32_t* mem; const uint32_t* addr; size_t mem_len; };
-__global__ void __launch_bounds__(256) k_gather_merge(const GatherArgs* __restrict__ args, size_t count, size_t n, size_t padded, uint32_t* __restrict__ out, uint32_t* __restrict__ oob) {
+__global__ void __launch_bounds__(256) k_gather_merge(const GatherArgs* __restrict__ args, size_t count, size_t n, size_t padded, uint32_t* __restrict__ out, uint32_t* __restrict__ oob,
+                                                      int rshift, size_t row0, size_t rstep) {
   for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t gt = rshift < 0 ? t : ((((t >> rshift) * rstep + row0) << rshift) | (t & (((size_t)1 << rshift) - 1)));     // index into the whole polynomial
     Fr v = fe_zero<FrP>();
-    if (t < count * n) {
-      const size_t k = t / n, i = t - k * n;
+    if (gt < count * n) {
+      const size_t k = gt / n, i = gt - k * n;
       const GatherArgs a = args[k];
       const uint32_t idx = a.addr[i];
       if (idx < a.mem_len) v = fe_load<FrP>(a.mem + 8 * (size_t)idx); else atomicAdd(oob, 1u);   // sparse_mlpoly_full.rs:228 assert!(addr < num_cells)

@@ -122,3 +122,43 @@ def test_shard_ranges(sbn):
     assert rows == list(range(4096))
     # zero-padding rows 3072.. (hyrax.rs:245) spread evenly over the ranks
     assert all(sum(1 for x in sharding.shard_rows(4096, r, 8) if x >= 3072) == 128 for r in range(8))
+
+
+def test_cols_headroom_arithmetic():
+    """fp.cuh's 64-bit product columns (`Cols`): the callers accumulate up to `pend == 6` products between carry passes and then
+    run the reduction on top (sumcheck_comb_kernels.cuh).  With the limb width and count parsed from the shipped sources, the
+    worst case (every operand limb at its maximum) must stay below 2^64 — an edit to the limb layout or to the callers' carry
+    interval that breaks the bound fails here.  (tools/micro/fptest runs the same worst case on the device.)"""
+    cs = os.path.join(ROOT, "spartan-bn254_amd", "csrc")
+    fp = open(os.path.join(cs, "fp.cuh")).read()
+    nl = int(re.search(r"constexpr int NL = (\d+);", fp).group(1))
+    bits = int(re.search(r"constexpr uint32_t LMASK = \(1u << (\d+)\) - 1;", fp).group(1))
+    assert nl * bits >= 256 + 5
+    lmax = (1 << bits) - 1
+    pend = set()
+    for f in ("sumcheck_comb_kernels.cuh", "sumcheck_kernels.cuh", "g1.cuh", "msm_kernels.cuh", "comb_kernels.cuh"):
+        pend |= {int(x) for x in re.findall(r"pend == (\d+)", open(os.path.join(cs, f)).read())}
+    assert pend, "no carry interval found in the kernels"
+    for cap in pend:
+        after_carry = lmax + (1 << (64 - bits))              # a column after cols_carry: below 2^bits, plus the carry that came in from below
+        worst = after_carry + cap * nl * lmax * lmax          # `cap` products of nl limb products each in the middle column
+        worst += nl * lmax * lmax                            # the reduction: nl quotient digits (< 2^bits) times modulus limbs (< 2^bits)
+        worst += worst >> bits                               # the carry the reduction moves up from the column below
+        assert worst < 1 << 64, f"Cols overflow with {cap} products between carry passes ({worst.bit_length()} bits)"
+    # the lazy two-product form (g1.cuh: Y3): one operand's limbs below 2^30.6
+    lazy = int(2 ** 30.6)
+    assert 2 * nl * lmax * lazy + nl * lmax * lmax + (1 << 36) < 1 << 64
+
+
+def test_sc_grids_clamped_to_partial_area():
+    """every grid of the combined sumcheck kernels is clamped to the partial-sum area (SC_PART_*_BLOCKS), whatever SBN_SC_* says"""
+    src = open(os.path.join(ROOT, "spartan-bn254_amd", "csrc", "abi_sumcheck.inc")).read()
+    assert "static_assert(SC_PARTIAL_BYTES ==" in src
+    for name in ("gxc", "gxs", "gx_seq"):
+        m = re.search(r"const unsigned %s = ([^;]*);" % name, src)
+        assert m and "SC_PART_" in m.group(1), name
+    for m in re.finditer(r"const unsigned gx = ([^;]*);", src):
+        assert "SC_PART_" in m.group(1), m.group(0)
+    # no environment lookup on a round's path any more
+    for f in ("abi_sumcheck.inc", "abi_tables.inc", "abi_bullet.inc"):
+        assert "getenv(" not in open(os.path.join(ROOT, "spartan-bn254_amd", "csrc", f)).read(), f

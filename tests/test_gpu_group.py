@@ -34,6 +34,83 @@ def test_group_commit_rows_one_matrix_interleaved(group, ol, L, R):
     gb.free()
 
 
+@pytest.mark.parametrize("L,R", [(2, 64), (10, 64), (32, 128)])
+def test_group_commit_rows_dev_interleaved(group, ol, L, R):
+    """sbn_group_commit_rows_dev: the matrix is ALREADY on the devices, context d holding the rows d, d + 3, ... (hyrax.rs:253-267 over
+    device-resident rows); canonical and ark-Montgomery scalars, with and without blinds, ragged row counts, fewer rows than contexts"""
+    import torch
+    import numpy as np
+    N = 3
+    gb, gxy = group.gens_new(R, b"gens_r1cs_eval")
+    Z = rand_scalars(L * R, 500 + L); bl = rand_scalars(L, 600 + L)
+    want = ol.commit_rows(Z, None, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    want_b = ol.commit_rows(Z, bl, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    Zn = np.frombuffer(Z, dtype=np.uint8).reshape(L, R * 32); Bn = np.frombuffer(bl, dtype=np.uint8).reshape(L, 32)
+    zs = [torch.from_numpy(np.ascontiguousarray(Zn[d::N])).cuda() for d in range(N)]
+    bs = [torch.from_numpy(np.ascontiguousarray(Bn[d::N])).cuda() for d in range(N)]
+    torch.cuda.synchronize()
+    zp = [t.data_ptr() if t.numel() else 0 for t in zs]; bp = [t.data_ptr() if t.numel() else 0 for t in bs]
+    out, inf = group.commit_rows_dev(gb, zp, None, L, R)
+    assert out == want and not any(inf)
+    assert group.commit_rows_dev(gb, zp, bp, L, R)[0] == want_b
+    group.bases_precompute(gb, 8 << 20)
+    assert group.commit_rows_dev(gb, zp, bp, L, R)[0] == want_b
+    assert group.commit_rows_dev(gb, zp, None, L, R)[0] == want == group.commit_rows(gb, Z, None, L, R)[0]
+    gb.free()
+
+
+@pytest.mark.parametrize("log_n,count,log_mem,R", [(6, 6, 5, 32), (8, 6, 7, 64), (7, 3, 6, 16), (5, 5, 4, 8)])
+def test_group_gather_commit_derefs(group, ol, pr, log_n, count, log_mem, R):
+    """sbn_group_gather_commit: Derefs::commit over the group from device-resident inputs (sparse_mlpoly_full.rs:245-257, 293-297, 301-304):
+    the eq tables are built on every context, each context gathers and commits only its interleaved rows of the merged polynomial.  Against
+    the oracle's row commitments of the host-side gather, and against the single-context sbn_gather_merge + sbn_commit_table."""
+    import torch
+    import numpy as np
+    N = 3
+    n = 1 << log_n; nmem = 1 << log_mem
+    padded = 1
+    while padded < count * n:
+        padded <<= 1
+    L = padded // R
+    rng = np.random.default_rng(1000 + log_n + count)
+    addrs = [rng.integers(0, nmem, size=n, dtype=np.uint32) for _ in range(count)]
+    rx = rand_scalars(log_mem, 701); ry = rand_scalars(log_mem, 702)
+    eqs_host = [ol.eq_evals(rx), ol.eq_evals(ry)]
+    comb = b"".join(b"".join(eqs_host[k % 2][32 * int(a):32 * int(a) + 32] for a in addrs[k]) for k in range(count))
+    comb += bytes(32 * (padded - count * n))
+    gb, gxy = group.gens_new(R, b"gens_r1cs_eval")
+    want = ol.commit_rows(comb, None, L, R, gxy[:64 * R], gxy[64 * R:], 4)
+    mem, aptr, keep = [], [], []
+    for d in range(N):
+        cx = group.ctx(d)
+        tx, ty = cx.eq_evals(rx), cx.eq_evals(ry)
+        at = [torch.from_numpy(a.view(np.int32)).cuda() for a in addrs]
+        keep.append((tx, ty, at))
+        mem.append([tx if k % 2 == 0 else ty for k in range(count)])
+        aptr.append([t.data_ptr() for t in at])
+    torch.cuda.synchronize()
+    out, inf = group.gather_commit(gb, mem, aptr, n, L, R)
+    assert out == want
+    assert all(bool(inf[i]) == (out[64 * i:64 * i + 64] == bytes(64)) for i in range(L))
+    # the one-context form of the same commitment
+    c0 = group.ctx(0)
+    t = c0.gather_merge(mem[0], aptr[0], n)
+    assert c0.table_download(t) == comb
+    t.free()
+    # one context's share on its own: rows 1, 4, 7, ...
+    rows1 = len(range(1, L, N))
+    if rows1:
+        t1 = c0.gather_merge_rows(mem[0], aptr[0], n, R, 1, N, rows1)
+        assert len(t1) == rows1 * R
+        assert c0.table_download(t1) == b"".join(comb[32 * R * r:32 * R * (r + 1)] for r in range(1, L, N))
+        t1.free()
+    with pytest.raises(Exception):
+        c0.gather_merge_rows(mem[0], aptr[0], n, R, 1, N, rows1 + 1)          # a row outside the matrix
+    for tx, ty, _ in keep:
+        tx.free(); ty.free()
+    gb.free()
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 1000, 1 << 14])
 def test_group_msm_base_point_ranges(group, ol, n):
     """ONE MSM cut into contiguous base-point ranges, the per-context partial sums folded on the host (group.rs:171-175 + the `+` of

@@ -664,22 +664,37 @@ def test_stateful_sumcheck_combined_kernels(ctx, ol, logn, n_par, n_seq):
     _run_stateful_sumcheck(ctx, ol, 1 << logn, n_par, n_seq, 7500 + 10 * logn + n_par)
 
 
-def test_stateful_sumcheck_modes_agree(ctx, ol, pr):
+def test_stateful_sumcheck_modes_agree(ctx, sbn, ol, pr):
     """a zero coefficient among the "par" instances (no inverse: nothing is scaled, the host weighs every triple), and SBN_SC_NO_COMB /
     SBN_SC_NO_COMB_KERNEL forcing the other two modes onto a size the combined kernels would take, SBN_SC_NO_MIXED the separate launches of
-    the "par" groups and the "seq" instances: all equal to the oracle"""
+    the "par" groups and the "seq" instances, SBN_SC_NO_MIXED_EVAL the two-launch round 0 (k_sc_comb_eval + k_sc_eval with n_seq > 0 on
+    2^17-entry tables): all equal to the oracle.  The overrides are read when a context is created: a fresh context per variant."""
     import os
     co = bytearray(rand_scalars(8, 4242)); co[32:64] = bytes(32)
     _run_stateful_sumcheck(ctx, ol, 1 << 15, 5, 3, 7900, bytes(co))
     _run_stateful_sumcheck(ctx, ol, 1 << 6, 5, 3, 7910, bytes(co))
     one = (1).to_bytes(32, "little"); top = (pr.R - 1).to_bytes(32, "little")
     _run_stateful_sumcheck(ctx, ol, 1 << 15, 3, 1, 7920, one + top + one + top)              # coefficients 1 and r - 1
-    for var in ("SBN_SC_NO_COMB", "SBN_SC_NO_COMB_KERNEL", "SBN_SC_NO_MIXED"):
+    for var, logn in (("SBN_SC_NO_COMB", 16), ("SBN_SC_NO_COMB_KERNEL", 16), ("SBN_SC_NO_MIXED", 17), ("SBN_SC_NO_MIXED_EVAL", 17)):
         os.environ[var] = "1"
         try:
-            _run_stateful_sumcheck(ctx, ol, 1 << 16, 4, 2, 7930)
+            cx = sbn.Context(0)
         finally:
             del os.environ[var]
+        try:
+            _run_stateful_sumcheck(cx, ol, 1 << logn, 4, 2, 7930 + logn)
+        finally:
+            cx.close()
+    # grids asked for beyond the partial-sum area are clamped (ADVICE r3): 2^18-entry tables, 4096 blocks per group requested
+    os.environ["SBN_SC_COMB_GRID"] = "4096"; os.environ["SBN_SC_COMB_EVAL_BLOCKS"] = "65536"
+    try:
+        cx = sbn.Context(0)
+    finally:
+        del os.environ["SBN_SC_COMB_GRID"]; del os.environ["SBN_SC_COMB_EVAL_BLOCKS"]
+    try:
+        _run_stateful_sumcheck(cx, ol, 1 << 18, 3, 1, 7990)
+    finally:
+        cx.close()
 
 
 def test_stateful_sumcheck_errors(ctx, sbn, pr):
@@ -689,6 +704,11 @@ def test_stateful_sumcheck_errors(ctx, sbn, pr):
         ctx.sumcheck_begin([a], [short], c2, [], [], [], rand_scalars(1, 5))                 # lengths differ
     with pytest.raises(sbn.SbnError):
         ctx.sumcheck_begin([a], [b], c2, [], [], [], pr.R.to_bytes(32, "little"))          # non-canonical coefficient
+    # a NULL entry among the "seq" C tables with no "par" instance: SBN_EINVAL, not a crash
+    import ctypes as C
+    one = (C.c_void_p * 1)(a.h); nul = (C.c_void_p * 1)(None); sth = C.c_void_p(); o96 = (C.c_uint8 * 96)()
+    co1 = (C.c_uint8 * 32).from_buffer_copy(rand_scalars(1, 5))
+    assert sbn.lib().sbn_sumcheck_begin(ctx.h, None, None, None, C.c_size_t(0), one, one, nul, C.c_size_t(1), co1, o96, C.byref(sth)) == -1
     st, _ = ctx.sumcheck_begin([a], [b], c2, [], [], [], rand_scalars(1, 5))
     with pytest.raises(sbn.SbnError):
         st.finish()                                                                         # variables left

@@ -71,6 +71,31 @@ template <class M> __global__ void k_inv(const uint32_t* in, uint32_t* bad, int 
   const Fe<M> ai = fe_inv<M>(a), one = fe_mul<M>(a, ai);
   if (!fe_eq<M>(one, fe_one<M>())) atomicAdd(bad, 1u);
 }
+// Headroom of the 64-bit product columns (fp.cuh: Cols): the documented capacity is 6 products between carry passes + the reduction's own
+// 9 x 2^58; the worst case is every operand limb = 2^29 - 1.  6 products, a carry pass, 6 more, ONE reduction must equal twelve single
+// products added up (any column overflow would change the value).  The callers' pattern (sumcheck_comb_kernels.cuh: `pend == 6`).
+template <class M> __global__ void k_cols_worst(uint32_t* bad) {
+  Fe<M> a; for (int k = 0; k < NL; k++) a.v[k] = LMASK;                       // every limb at its maximum ...
+  a.v[NL - 1] = 0x007fffffu;                                                  // ... except the top one: a VALUE below 2^255 (table values are below 2.5 r; the sum must fit 261 bits after the reduction)
+  Cols s; cols_zero(s);
+  for (int i = 0; i < 6; i++) cols_mac<M>(s, a, a);
+  cols_carry(s);
+  for (int i = 0; i < 6; i++) cols_mac<M>(s, a, a);
+  const Fe<M> got = cols_reduce<M>(s);
+  const Fe<M> one = fe_mulu<M>(a, a);
+  Fe<M> want = fe_zero<M>();
+  for (int i = 0; i < 12; i++) want = fe_reduce<M>(fe_add<M>(want, one));
+  if (!fe_eq<M>(got, want)) atomicAdd(bad, 1u);
+  // and the two-product forms with one lazy operand (limbs below 2^30.6: cols_mac_lazy's documented bound), as xyzz_madd's Y3 uses them
+  Fe<M> b; for (int k = 0; k < NL; k++) b.v[k] = 0x5fffffffu;                 // just below 2^30.6
+  b.v[NL - 1] = 0x003fffffu;
+  Cols t; cols_zero(t);
+  cols_mac_lazy<M>(t, a, b); cols_mac_lazy<M>(t, a, b);
+  const Fe<M> got2 = cols_reduce<M>(t);
+  const Fe<M> bn = fe_normu<M>(b);
+  const Fe<M> w1 = fe_mulu<M>(a, bn);
+  if (!fe_eq<M>(got2, fe_reduce<M>(fe_add<M>(w1, w1)))) atomicAdd(bad + 1, 1u);
+}
 constexpr int MM_ITERS = 512;
 template <class M, int VAR> __global__ void __launch_bounds__(256) k_rate(uint32_t* o, const uint32_t* in) {
   typedef typename Leg<M>::T LM;
@@ -146,6 +171,14 @@ int main() {
     else hipLaunchKernelGGL(k_inv<FqP>, dim3(4096 / 256), dim3(256), 0, 0, d_in, d_bad, 4096);
     CK(hipMemcpy(bad, d_bad, 4, hipMemcpyDeviceToHost));
     printf("%s inv check: %u mismatches of 4096\n", f ? "Fr" : "Fq", bad[0]); fails += bad[0];
+  }
+  {
+    CK(hipMemset(d_bad, 0, 128));
+    hipLaunchKernelGGL(k_cols_worst<FqP>, dim3(1), dim3(1), 0, 0, d_bad); hipLaunchKernelGGL(k_cols_worst<FrP>, dim3(1), dim3(1), 0, 0, d_bad + 2);
+    uint32_t bad[4]; CK(hipMemcpy(bad, d_bad, 16, hipMemcpyDeviceToHost));
+    printf("Cols headroom, all limbs 2^29 - 1, 6 + 6 products and one reduction: Fq %s, Fr %s; two lazy products (limbs < 2^30.6): Fq %s, Fr %s\n",
+           bad[0] ? "OVERFLOW" : "ok", bad[2] ? "OVERFLOW" : "ok", bad[1] ? "OVERFLOW" : "ok", bad[3] ? "OVERFLOW" : "ok");
+    fails += bad[0] + bad[1] + bad[2] + bad[3];
   }
   for (int occ : {1, 2, 3, 4, 8}) {      // occ = waves per SIMD (256-thread blocks per CU)
     rate("fe_mul (legacy 8x32)", k_rate<FqP, 0>, 256 * occ, 2.0 * MM_ITERS, d_o, d_in);
