@@ -173,6 +173,8 @@ def summarize(line):
     gr = line.get("group")
     if isinstance(gr, dict):
         s["group"] = {k: (v.get("ms_per_commit") or v.get("ms_per_commit_incl_pcie") or v.get("ms_per_msm")) for k, v in gr.items() if isinstance(v, dict)}
+    if isinstance(line.get("collective"), dict):
+        s["collective"] = {k: line["collective"].get(k) for k in ("backend", "world_size", "rccl_version", "all_gather_calls", "device_tensors")}
     cb = line.get("cpu_baseline")
     if isinstance(cb, dict):
         s["cpu_points_per_s"] = {"cores_%d" % cb.get("cores", 0): cb.get("value"), "cores_1": g(cb, "one_thread", "value")}
@@ -653,6 +655,13 @@ def main():
                            "sharding": sharding_desc, "parity": "bit-exact vs the discrete-log identity / CPU oracle, checked before timing"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_avg_ms": kernel_avgs(prof), "serial_reference": serial}
         line.update(line_extra)
+        if use_coll:
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+            except Exception:
+                ver = None
+            line["collective"] = dict(sharding.STATS, backend=dist.get_backend(), world_size=world, rccl_version=ver, forced_at_world_size_1=bool(args.force_collective),
+                                      note="every partial sum / row commitment of this run went through torch.distributed all_gather on uint8 tensors (sharding.py)")
         line["summary"] = summarize(line)          # LAST key: the driver keeps only the tail of a long line
         print(json.dumps(line), flush=True)
     for cx in ctxs:

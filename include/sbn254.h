@@ -168,6 +168,12 @@ typedef struct sbn_sumcheck sbn_sumcheck;
 int sbn_sumcheck_begin(sbn_ctx* ctx, const sbn_table* const* A_par, const sbn_table* const* B_par, const sbn_table* C_par, size_t n_par,
                        const sbn_table* const* A_seq, const sbn_table* const* B_seq, const sbn_table* const* C_seq, size_t n_seq,
                        const uint8_t* coeffs, uint8_t out_evals[96], sbn_sumcheck** out);
+/* The same with poly_C_par = EqPolynomial::new(rand).evals() built inside the call (product_tree.rs:267-275: how every layer of
+ * ProductCircuitEvalProofBatched::prove makes its C): rand = ell canonical scalars, 2^ell = the tables' length; the eq table belongs to the
+ * state (its final claim is listed where C_par's is).  One call per layer instead of sbn_eq_evals + sbn_sumcheck_begin + sbn_table_free. */
+int sbn_sumcheck_begin_eq(sbn_ctx* ctx, const sbn_table* const* A_par, const sbn_table* const* B_par, size_t n_par, const uint8_t* rand, size_t ell,
+                          const sbn_table* const* A_seq, const sbn_table* const* B_seq, const sbn_table* const* C_seq, size_t n_seq,
+                          const uint8_t* coeffs, uint8_t out_evals[96], sbn_sumcheck** out);
 /* bind every table to r_j (sumcheck.rs:289-299); out_evals = the combined sums of the next round (zeros after the last bind) */
 int sbn_sumcheck_round(sbn_ctx* ctx, sbn_sumcheck* st, const uint8_t r[32], uint8_t out_evals[96]);
 size_t sbn_sumcheck_len(const sbn_sumcheck* st);                       /* current table length (halves per round) */
@@ -192,7 +198,7 @@ int sbn_table_evaluate_many(sbn_ctx* ctx, const sbn_table* const* Z, size_t coun
 int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn_table** out);
 
 /* ---- BulletReductionProof::prove (nizk/bullet.rs:41-126) as a device-resident state; the transcript stays with the caller:
- *      begin, then per round cross -> (absorb L, R; squeeze u) -> fold, then finish.
+ *      begin, cross (the first round's L, R), then per challenge u: fold_cross(u) -> the next L, R (fold(u) for the last one), then finish.
  * The generators are never folded (bullet.rs:87-91 costs n 254-bit scalar multiplications per round): round j's L and R are
  * MSMs over the ORIGINAL generators with scalars a[..] * s_t, s_t the running product of the u / u_inv the fold would have
  * applied to G_t (the verifier's compute_s, bullet.rs:181-199); g_hat = MSM(s, G).  Same group elements, bit for bit. ----
@@ -212,6 +218,11 @@ int sbn_bullet_cross(sbn_ctx* ctx, sbn_bullet* st, const uint8_t* blind_L, const
 /* The folds after the challenge u (bullet.rs:86-106): G <- u_inv*G_L + u*G_R (kept as coefficients), a <- u*a_L + u_inv*a_R,
  * b <- u_inv*b_L + u*b_R; the length halves. */
 int sbn_bullet_fold(sbn_ctx* ctx, sbn_bullet* st, const uint8_t u[32], const uint8_t u_inv[32]);
+/* The loop body of bullet.rs:63-108 as ONE call per challenge: fold with u (as sbn_bullet_fold), then the cross terms of the NEXT round
+ * (as sbn_bullet_cross) on the folded vectors — one launch ahead of the commit, one host wait.  Needs length >= 4 (after the fold at
+ * least one more round follows); the last challenge goes to sbn_bullet_fold.  Same L, R, c_L, c_R as the two separate calls. */
+int sbn_bullet_fold_cross(sbn_ctx* ctx, sbn_bullet* st, const uint8_t u[32], const uint8_t u_inv[32], const uint8_t* blind_L, const uint8_t* blind_R,
+                          uint8_t L_xy[64], int* L_is_inf, uint8_t R_xy[64], int* R_is_inf, uint8_t c_L[32], uint8_t c_R[32]);
 /* After the last fold (length 1): a_hat, b_hat, g_hat (bullet.rs:114-120) */
 int sbn_bullet_finish(sbn_ctx* ctx, sbn_bullet* st, uint8_t a_hat[32], uint8_t b_hat[32], uint8_t g_hat_xy[64], int* g_hat_is_inf);
 

@@ -15,10 +15,10 @@ EXPORTED_SYMBOLS = [
     "sbn_table_upload", "sbn_table_from_dev", "sbn_table_free", "sbn_table_len", "sbn_table_download", "sbn_table_read0", "sbn_table_read0_many",
     "sbn_bind_top", "sbn_bind_top_many", "sbn_sc_eval_cubic", "sbn_sc_eval_cubic_batched", "sbn_sc_eval_r1cs", "sbn_sc_eval_quad",
     "sbn_sc_bind_eval_cubic_batched", "sbn_sc_bind_eval_r1cs", "sbn_sc_bind_eval_quad",
-    "sbn_sumcheck_begin", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
+    "sbn_sumcheck_begin", "sbn_sumcheck_begin_eq", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
     "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_commit_rows_dev", "sbn_group_gather_commit", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -80,7 +80,7 @@ HARNESS_STAGES = ["r1cs_sat_proof", "eq_evals", "derefs_computation", "derefs_co
 class HarnessParams(C.Structure):
     _fields_ = [("log_ops", C.c_int32), ("log_mem", C.c_int32), ("log_cons", C.c_int32), ("stateful_sumcheck", C.c_int32),
                 ("lookup_bytes_sat", C.c_uint64), ("lookup_bytes_eval", C.c_uint64), ("seed", C.c_uint64), ("rounds_out", C.c_uint32 * 4),
-                ("passes", C.c_uint32), ("reserved", C.c_uint32)]
+                ("passes", C.c_uint32), ("trace_markers", C.c_uint32)]
 
 
 _HARNESS = None
@@ -98,11 +98,12 @@ def harness_lib():
     return _HARNESS
 
 
-def harness_prove(ctx, log_ops, log_mem, log_cons, stateful=True, lookup_bytes_sat=0, lookup_bytes_eval=0, seed=1, trace_cap=0, passes=1):
+def harness_prove(ctx, log_ops, log_mem, log_cons, stateful=True, lookup_bytes_sat=0, lookup_bytes_eval=0, seed=1, trace_cap=0, passes=1, trace_markers=False):
     """a keyless-shaped prove's device-side stages from compiled code -> (stage_ms dict, digest, trace bytes, rounds dict); with passes > 1
     the proves run back to back on one setup and the fastest pass's times are returned (the trace is the last pass's)"""
     prm = HarnessParams(log_ops, log_mem, log_cons, 1 if stateful else 0, lookup_bytes_sat, lookup_bytes_eval, seed)
     prm.passes = passes
+    prm.trace_markers = 1 if trace_markers else 0
     ms = (C.c_double * 16)(); dig = (C.c_uint8 * 32)(); err = C.create_string_buffer(512)
     tr = (C.c_uint8 * trace_cap)() if trace_cap else None; tl = C.c_size_t(0)
     rc = harness_lib().sbn_harness_prove(ctx.h, C.byref(prm), ms, dig, tr, C.c_size_t(trace_cap), C.byref(tl), err, C.c_size_t(512))
@@ -517,6 +518,14 @@ class Context:
                                            mk(A_seq), mk(B_seq), mk(C_seq), C.c_size_t(len(A_seq)), _ptr(coeffs), out, C.byref(st)), "sbn_sumcheck_begin")
         return Sumcheck(self, st, len(A_par), len(A_seq)), bytes(out)
 
+    def sumcheck_begin_eq(self, A_par, B_par, rand, A_seq, B_seq, C_seq, coeffs):
+        """poly_C_par = eq(rand) built inside the call -> (Sumcheck state, the combined (e0, e2, e3) of round 0)"""
+        mk = lambda ts: (C.c_void_p * max(1, len(ts)))(*[t.h for t in ts])
+        st = C.c_void_p(); out = (C.c_uint8 * 96)()
+        self._chk(lib().sbn_sumcheck_begin_eq(self.h, mk(A_par), mk(B_par), C.c_size_t(len(A_par)), _ptr(rand), C.c_size_t(len(rand) // 32),
+                                              mk(A_seq), mk(B_seq), mk(C_seq), C.c_size_t(len(A_seq)), _ptr(coeffs), out, C.byref(st)), "sbn_sumcheck_begin_eq")
+        return Sumcheck(self, st, len(A_par), len(A_seq)), bytes(out)
+
     def eq_evals(self, r):
         ell = len(r) // 32; ht = C.c_void_p()
         self._chk(lib().sbn_eq_evals(self.h, _ptr(r), C.c_size_t(ell), C.byref(ht)), "sbn_eq_evals"); return Table(self, ht)
@@ -585,6 +594,13 @@ class Context:
         Lo, Ro = (C.c_uint8 * 64)(), (C.c_uint8 * 64)(); li, ri = C.c_int(0), C.c_int(0)
         cl, cr = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
         self._chk(lib().sbn_bullet_cross(self.h, st.h, _ptr(blind_L), _ptr(blind_R), Lo, C.byref(li), Ro, C.byref(ri), cl, cr), "sbn_bullet_cross")
+        return bytes(Lo), bool(li.value), bytes(Ro), bool(ri.value), bytes(cl), bytes(cr)
+
+    def bullet_fold_cross(self, st, u, u_inv, blind_L=None, blind_R=None):
+        """fold with u, then the next round's cross terms -> (L_xy, L_inf, R_xy, R_inf, c_L, c_R)"""
+        Lo, Ro = (C.c_uint8 * 64)(), (C.c_uint8 * 64)(); li, ri = C.c_int(0), C.c_int(0)
+        cl, cr = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+        self._chk(lib().sbn_bullet_fold_cross(self.h, st.h, _ptr(u), _ptr(u_inv), _ptr(blind_L), _ptr(blind_R), Lo, C.byref(li), Ro, C.byref(ri), cl, cr), "sbn_bullet_fold_cross")
         return bytes(Lo), bool(li.value), bytes(Ro), bool(ri.value), bytes(cl), bytes(cr)
 
     def bullet_fold(self, st, u, u_inv):

@@ -365,6 +365,7 @@ struct RowInfo {
   size_t col_value = ~(size_t)0, col_blind = ~(size_t)0;   // the only columns a flagged row can be non-zero in
   bool internal_rows = false;       // rows written by this library (bullet rounds): canonical and never constant, so the pass that
                                     // classifies rows and checks the caller's scalars is skipped
+  bool mont_scalars = false;        // dZ / dBl are table values (Montgomery R = 2^261, lazy): only with merged bases — the merge converts on the way out
 };
 static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint32_t* d_xy, uint8_t* d_inf, const RowInfo& ri = RowInfo()) {
   if (L == 0) return SBN_OK;
@@ -374,15 +375,17 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     const size_t U = b->U; int rc;
     if ((rc = ensure(c, c->merged, L * (U + 1) * 32 + L))) return rc;
     uint32_t* m = (uint32_t*)c->merged.p; uint8_t* rowflags = (uint8_t*)c->merged.p + L * (U + 1) * 32;
-    if (R && !ri.internal_rows) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, c->d_bad);
+    if (ri.internal_rows) rowflags = nullptr;          // no classification pass, no flags to clear (a 1-byte fill was a launch of its own)
+    else if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, ri.mont_scalars ? (uint32_t*)nullptr : c->d_bad);
     else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
-    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m);
-    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m);
+    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m, ri.mont_scalars ? 1 : 0);
+    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m, ri.mont_scalars ? 1 : 0);
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
     RowInfo info; info.flags = rowflags; info.skip_zero = dBl == nullptr;      // with blinds a zero row still commits to blind*h
     info.col_value = U; info.col_blind = (dBl && b->hcol <= U) ? (size_t)b->hcol : ~(size_t)0;
     return commit_rows_launch(c, b->uniq, m, nullptr, L, U + 1, d_xy, d_inf, info);
   }
+  if (ri.mont_scalars) return fail(c, SBN_EINVAL, "commit: internal: Montgomery scalars without merged bases");
   const size_t ncol = R + (dBl ? 1 : 0);
   if (ncol == 0) {
     if (!d_xy) { int rc0; if ((rc0 = ensure(c, c->wsum, L * 128))) return rc0; HIPCHK(c, hipMemsetAsync(c->wsum.p, 0, L * 128, c->stream)); return SBN_OK; }
@@ -437,7 +440,7 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   return SBN_OK;
 }
 // Hyrax row commits on device-resident canonical scalars (hyrax.rs:253-267 -> commitments.rs:144-154)
-static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf) {
+static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ, const uint32_t* dBl, size_t L, size_t R, uint8_t* out_xy, uint8_t* out_inf, const RowInfo& ri = RowInfo()) {
   if (L == 0) return SBN_OK;
   int rc;
   if ((rc = input_check_begin(c))) return rc;
@@ -446,7 +449,7 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     // the sums and the input-check counter go straight into the host mailbox, flag behind them (the sumcheck rounds' protocol):
     // one small launch and a poll instead of two copies and a stream synchronisation — a bullet round commits 2 rows at a time
     if ((rc = sc_tickets(c))) return rc;
-    if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, nullptr, nullptr))) return rc;
+    if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, nullptr, nullptr, ri))) return rc;
     const uint32_t seq = ++c->mbox_seq;
     uint32_t* hfin = c->mbox + SC_MBOX_FINALS;
     static_assert(16 * 32 + 1 <= SC_MBOX_WORDS - SC_MBOX_FINALS, "mailbox: 16 XYZZ sums + the counter must fit the final-claims area");
@@ -461,7 +464,7 @@ static int commit_rows_device(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
   }
   if ((rc = ensure(c, c->out_small, L * 65))) return rc;
   if ((rc = ensure_pin(c, std::max<size_t>(4096, L * 65)))) return rc;
-  if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64))) return rc;
+  if ((rc = commit_rows_launch(c, b, dZ, dBl, L, R, (uint32_t*)c->out_small.p, (uint8_t*)c->out_small.p + L * 64, ri))) return rc;
   HIPCHK(c, hipMemcpyAsync(c->pin, c->out_small.p, L * 65, hipMemcpyDeviceToHost, c->stream));
   if ((rc = input_check_fetch(c))) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));

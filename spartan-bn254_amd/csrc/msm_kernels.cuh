@@ -598,14 +598,14 @@ __global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restr
     const uint4 b0 = z[2 * j], b1 = z[2 * j + 1];
     diff |= (a0.x ^ b0.x) | (a0.y ^ b0.y) | (a0.z ^ b0.z) | (a0.w ^ b0.w) | (a1.x ^ b1.x) | (a1.y ^ b1.y) | (a1.z ^ b1.z) | (a1.w ^ b1.w);
     const uint32_t kk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    nbad += fe_is_canonical<FrP>(kk) ? 0 : 1;
+    nbad += (!bad || fe_is_canonical<FrP>(kk)) ? 0 : 1;          // bad == nullptr: table values (lazy Montgomery representatives), nothing to check
   }
   if (blinds && threadIdx.x == 0) {
     const uint4 b0 = reinterpret_cast<const uint4*>(blinds + 8 * row)[0], b1 = reinterpret_cast<const uint4*>(blinds + 8 * row)[1];
     const uint32_t kk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     nbad += fe_is_canonical<FrP>(kk) ? 0 : 1;
   }
-  if (nbad) atomicAdd(bad, (uint32_t)nbad);
+  if (nbad && bad) atomicAdd(bad, (uint32_t)nbad);
   const int any = __syncthreads_or(diff != 0);
   if (threadIdx.x == 0) flags[row] = any ? 0 : (((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w) == 0) ? 2 : 1);
 }
@@ -613,29 +613,32 @@ __global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restr
 // (or U+1 when the table has no h).
 __global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
                                                      const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
-                                                     const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out) {
+                                                     const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out, int internal) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t W1 = U + 1;
   if (t >= L * W1) return;
   const size_t row = t / W1, u = t - row * W1;
-  const bool cst = flags[row] != 0;
+  const bool cst = flags && flags[row] != 0;            // flags == nullptr: rows written by this library (bullet rounds), never constant
+  // internal != 0: Z (and the blinds) are this library's TABLE values (Montgomery R = 2^261, lazy representatives below 2.5 r: sbn_commit_table) —
+  // the sums are taken on them and leave Montgomery form here, on the way out: the merge reads every scalar anyway, so the separate
+  // conversion pass over the matrix (1 GiB read + 1 GiB written for the derefs commitment) disappears.
   // (copies of canonical input scalars are stored as they are; sums go through fe_store, which canonicalises: the digits are cut from them)
-  if (u == U) { fe_store_packed<FrP>(out + 8 * t, cst ? fe_load<FrP>(Z + 8 * row * R) : fe_zero<FrP>()); return; }
-  if (cst) { fe_store_packed<FrP>(out + 8 * t, (u == hcol && blinds) ? fe_load<FrP>(blinds + 8 * row) : fe_zero<FrP>()); return; }
+  if (u == U) { const Fr v = cst ? fe_load<FrP>(Z + 8 * row * R) : fe_zero<FrP>(); fe_store_packed<FrP>(out + 8 * t, internal ? fe_from_mont(v) : v); return; }
+  if (cst) { const Fr v = (u == hcol && blinds) ? fe_load<FrP>(blinds + 8 * row) : fe_zero<FrP>(); fe_store_packed<FrP>(out + 8 * t, internal ? fe_from_mont(v) : v); return; }
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   if (b - a > big_threshold) return;                     // k_merge_big owns it
   Fr acc = merged_load(Z, blinds, row, R, csr_cols[a]);
-  for (uint32_t j = a + 1; j < b; j++) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));
-  fe_store<FrP>(out + 8 * t, acc);
+  for (uint32_t j = a + 1; j < b; j++) acc = fe_add(acc, merged_load(Z, blinds, row, R, csr_cols[j]));      // <= MERGE_BIG terms (160 r at most)
+  if (internal) fe_store_packed<FrP>(out + 8 * t, fe_from_mont(fe_reduce(acc))); else fe_store<FrP>(out + 8 * t, acc);
 }
 // big groups: one block per (row, big group), four scalars in flight per lane (a bullet round merges 2 x 5381 scalars: one wave
 // with one load at a time was a chain of 84 exposed load latencies); constant rows were written by k_merge_small
 __global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
                                                    const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
-                                                   const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out) {
+                                                   const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out, int internal) {
   __shared__ uint32_t sm[4][NL];
   const size_t row = blockIdx.x / nbig; const uint32_t u = big_list[blockIdx.x % nbig];
-  if (flags[row]) return;
+  if (flags && flags[row]) return;
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   Fr acc = fe_zero<FrP>();
   uint32_t cnt = 0;
@@ -645,7 +648,7 @@ __global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ 
     const Fr x2 = j + 512 < b ? merged_load(Z, blinds, row, R, csr_cols[j + 512]) : fe_zero<FrP>();
     const Fr x3 = j + 768 < b ? merged_load(Z, blinds, row, R, csr_cols[j + 768]) : fe_zero<FrP>();
     acc = fe_add(fe_add(acc, x0), fe_add(fe_add(x1, x2), x3));
-    if (((cnt += 4) & 127u) == 0) acc = fe_reduce(acc);               // lazy values: keep the running sum far below the top limb's range
+    if (((cnt += 4) & (internal ? 31u : 127u)) == 0) acc = fe_reduce(acc);   // keep the running sum far below the top limb's range (table values reach 2.5 r: every 32 terms)
   }
   acc = fe_reduce(acc);
 #pragma unroll
@@ -656,7 +659,7 @@ __global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ 
   if (threadIdx.x == 0) {
     Fr s = acc;
     for (int w = 1; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
-    fe_store<FrP>(out + 8 * (row * (U + 1) + u), s);
+    if (internal) fe_store_packed<FrP>(out + 8 * (row * (U + 1) + u), fe_from_mont(fe_reduce(s))); else fe_store<FrP>(out + 8 * (row * (U + 1) + u), s);
   }
 }
 

@@ -549,9 +549,9 @@ __global__ void __launch_bounds__(256) k_fr_from_mont(const uint32_t* __restrict
     fe_store_packed<FrP>(out + 8 * i, fe_from_mont(fe_load<FrP>(in + 8 * i)));        // canonical plain integers
 }
 
-// one level of EqPolynomial::evals: out[2k+1] = in[k]*r_j ; out[2k] = in[k] - out[2k+1]   (hyrax.rs:360-366)
-__global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, const uint32_t* __restrict__ rj_mont) {
-  const Fr r = fe_load<FrP>(rj_mont);
+// one level of EqPolynomial::evals: out[2k+1] = in[k]*r_j ; out[2k] = in[k] - out[2k+1]   (hyrax.rs:360-366); r_j in Montgomery form, a kernel argument
+__global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, ScScalar rj) {
+  const Fr r = fr_from_words(rj);
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < size_in; k += (size_t)gridDim.x * blockDim.x) {
     Fr s = fe_load<FrP>(in + 8 * k);
     Fr hi = fe_mul(s, r);
@@ -560,8 +560,8 @@ __global__ void __launch_bounds__(256) k_eq_level(const uint32_t* __restrict__ i
   }
 }
 // two levels in one pass (r_j then r_{j+1}): in[k] -> out[4k .. 4k+3]; saves the intermediate table's write and re-read
-__global__ void __launch_bounds__(256) k_eq_level2(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, const uint32_t* __restrict__ rj_mont) {
-  const Fr r0 = fe_load<FrP>(rj_mont), r1 = fe_load<FrP>(rj_mont + 8);
+__global__ void __launch_bounds__(256) k_eq_level2(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t size_in, ScScalar rj0, ScScalar rj1) {
+  const Fr r0 = fr_from_words(rj0), r1 = fr_from_words(rj1);
   for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < size_in; k += (size_t)gridDim.x * blockDim.x) {
     const Fr s = fe_load<FrP>(in + 8 * k);
     const Fr h = fe_mul(s, r0), l = fe_sub(s, h);
@@ -572,27 +572,24 @@ __global__ void __launch_bounds__(256) k_eq_level2(const uint32_t* __restrict__ 
     fe_store_tab<FrP>(out + 8 * (4 * k + 3), hh);
   }
 }
-// the challenge vector as a kernel argument (no staging copy, no host wait): canonical -> Montgomery into r_mont[0..ell)
+// the first m <= EQ_DIRECT_MAX levels at once: out[i] = prod_j (bit_{m-1-j}(i) ? r_j : 1 - r_j), i < 2^m — the same field element the
+// level-by-level recurrence s -> (s - s r, s r) of hyrax.rs:360-366 produces (variable 0 is the most significant index bit).  The point
+// travels as a kernel argument, already in Montgomery form (one host product per coordinate): no staging copy, no conversion launch, no
+// host wait.  (Statically indexed selects: a dynamic index into a by-value argument would make the compiler copy it to scratch.)
 constexpr int EQ_MAX_VARS = 40;
-struct EqPoint { uint32_t v[EQ_MAX_VARS][8]; };
-__global__ void __launch_bounds__(64) k_eq_prepare(EqPoint r, int ell, uint32_t* __restrict__ r_mont) {
-  const int j = threadIdx.x;
-  if (j >= ell) return;
-  uint32_t w[8];
-#pragma unroll 1
-  for (int q = 0; q < EQ_MAX_VARS; q++) if (q == j) { for (int k = 0; k < 8; k++) w[k] = r.v[q][k]; }
-  fe_store<FrP>(r_mont + 8 * j, fe_to_mont(fe_unpack<FrP>(w)));
-}
-// the first m levels at once: out[i] = prod_j (bit_{m-1-j}(i) ? r_j : 1 - r_j), i < 2^m — the same field element the level-by-level
-// recurrence s -> (s - s r, s r) of hyrax.rs:360-366 produces (variable 0 is the most significant index bit)
-__global__ void __launch_bounds__(256) k_eq_direct(const uint32_t* __restrict__ r_mont, int m, uint32_t* __restrict__ out) {
+constexpr int EQ_DIRECT_MAX = 12;
+struct EqPoint { uint32_t v[EQ_DIRECT_MAX][8]; };
+__global__ void __launch_bounds__(256) k_eq_direct(EqPoint rp, int m, uint32_t* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ((size_t)1 << m)) return;
   const Fr one = fe_one<FrP>();
   Fr acc = one;
-  for (int j = 0; j < m; j++) {
-    const Fr r = fe_load<FrP>(r_mont + 8 * j);
-    acc = fe_mul(acc, ((i >> (m - 1 - j)) & 1) ? r : fe_sub(one, r));
+#pragma unroll
+  for (int j = 0; j < EQ_DIRECT_MAX; j++) {
+    if (j < m) {
+      const Fr r = fe_unpack<FrP>(rp.v[j]);
+      acc = fe_mul(acc, ((i >> (m - 1 - j)) & 1) ? r : fe_sub(one, r));
+    }
   }
   fe_store_tab<FrP>(out + 8 * i, acc);
 }

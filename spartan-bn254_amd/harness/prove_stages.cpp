@@ -125,7 +125,8 @@ struct sbn_harness_params {
   uint64_t seed;
   uint32_t rounds_out[4];                  // out: sumcheck rounds (ops, mem), bullet rounds, layers
   uint32_t passes;                         // >= 1: proves run back to back on ONE setup (generator sets, lookup tables, address arrays); the times of the fastest are returned
-  uint32_t reserved;
+  uint32_t trace_markers;                  // != 0 (profiling runs only): tiny marker launches (k_scalars_synthetic with 2 / 3 / 4 blocks) at every pass start and around
+                                           // every timed stage, OUTSIDE the timed regions, so that tools/trace_summary.py can cut a kernel trace into passes and stages
 };
 
 struct Harness {
@@ -152,15 +153,16 @@ struct Harness {
   }
   std::vector<uint8_t> cvec(size_t k) { std::vector<uint8_t> v(32 * k); for (size_t i = 0; i < k; i++) challenge(v.data() + 32 * i); return v; }
 
+  void marker(int blocks) { if (p->trace_markers && d_scratch) sbn_scalars_synthetic(ctx, 0, 0, (size_t)256 * (blocks - 1) + 1, d_scratch); }
   struct Timer { Harness* H; int a, b; std::chrono::steady_clock::time_point t0;
-    Timer(Harness* H_, int a_, int b_ = -1) : H(H_), a(a_), b(b_) { sbn_ctx_sync(H->ctx); t0 = std::chrono::steady_clock::now(); }
-    ~Timer() { sbn_ctx_sync(H->ctx); const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); H->ms[a] += d; if (b >= 0) H->ms[b] += d; } };
+    Timer(Harness* H_, int a_, int b_ = -1) : H(H_), a(a_), b(b_) { H->marker(3); sbn_ctx_sync(H->ctx); t0 = std::chrono::steady_clock::now(); }
+    ~Timer() { sbn_ctx_sync(H->ctx); const double d = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); H->ms[a] += d; if (b >= 0) H->ms[b] += d; H->marker(4); } };
 
+  void* d_scratch = nullptr; size_t scratch_bytes = 0;          // one staging buffer for every synthetic table (inputs of the prove: outside the timed stages)
   sbn_table* synth_table(size_t n, uint64_t stream) {
-    void* d = nullptr; chk(sbn_dev_alloc(ctx, n * 32, &d), "dev_alloc");
-    chk(sbn_scalars_synthetic(ctx, p->seed + stream, 0, n, d), "scalars_synthetic");
-    sbn_table* t = nullptr; chk(sbn_table_from_dev(ctx, d, n, 0, &t), "table_from_dev");
-    chk(sbn_dev_free(ctx, d), "dev_free");
+    if (n * 32 > scratch_bytes) { if (d_scratch) chk(sbn_dev_free(ctx, d_scratch), "dev_free"); d_scratch = nullptr; chk(sbn_dev_alloc(ctx, n * 32, &d_scratch), "dev_alloc"); scratch_bytes = n * 32; }
+    chk(sbn_scalars_synthetic(ctx, p->seed + stream, 0, n, d_scratch), "scalars_synthetic");
+    sbn_table* t = nullptr; chk(sbn_table_from_dev(ctx, d_scratch, n, 0, &t), "table_from_dev");
     return t;
   }
   void* upload_u32(const std::vector<uint32_t>& v) { void* d = nullptr; chk(sbn_dev_alloc(ctx, v.size() * 4, &d), "dev_alloc"); chk(sbn_dev_upload(ctx, d, v.data(), v.size() * 4), "dev_upload"); return d; }
@@ -180,13 +182,18 @@ struct Harness {
       uint8_t blind[32]; challenge(blind);
       uint8_t gamma[64]; int ginf = 0;
       chk(sbn_bullet_begin(ctx, G, Q, LZ, Rv, blind, gamma, &ginf, &st), "bullet_begin"); absorb(0x41, gamma, 64);
+      // bullet.rs:63-108: per round (blinds from the tape), L and R into the transcript, the challenge u, the folds.  One ABI call per
+      // challenge: sbn_bullet_fold_cross folds with u and returns the NEXT round's L, R (the blinds of that round are drawn first, as the
+      // reference draws them at the top of its loop body, before L and R exist)
+      uint8_t LR[128], cl[32], cr[32]; int li = 0, ri = 0;
+      uint8_t bl[32], br[32];
+      if (log_r) { challenge(bl); challenge(br); chk(sbn_bullet_cross(ctx, st, bl, br, LR, &li, LR + 64, &ri, cl, cr), "bullet_cross"); }
       for (size_t rnd = 0; rnd < log_r; rnd++) {
-        uint8_t bl[32], br[32]; challenge(bl); challenge(br);
-        uint8_t LR[128], cl[32], cr[32]; int li = 0, ri = 0;
-        chk(sbn_bullet_cross(ctx, st, bl, br, LR, &li, LR + 64, &ri, cl, cr), "bullet_cross"); absorb(0x42, LR, 128);
+        absorb(0x42, LR, 128);
         uint8_t u[32]; challenge(u);
         El ue; memcpy(ue.v, u, 32); const El ui = fr_inv(ue);
-        chk(sbn_bullet_fold(ctx, st, u, (const uint8_t*)ui.v), "bullet_fold");
+        if (rnd + 1 < log_r) { challenge(bl); challenge(br); chk(sbn_bullet_fold_cross(ctx, st, u, (const uint8_t*)ui.v, bl, br, LR, &li, LR + 64, &ri, cl, cr), "bullet_fold_cross"); }
+        else chk(sbn_bullet_fold(ctx, st, u, (const uint8_t*)ui.v), "bullet_fold");
         p_rounds_bullet++;
       }
       uint8_t fin[128]; int gi = 0;
@@ -207,7 +214,7 @@ struct Harness {
       else chk(sbn_bind_top_many(ctx, T.data(), T.size(), r), "bind_top_many");
     }
     std::vector<uint8_t> fin(32 * T.size());
-    for (size_t i = 0; i < T.size(); i++) chk(sbn_table_read0(ctx, T[i], fin.data() + 32 * i), "read0");
+    chk(sbn_table_read0_many(ctx, T.data(), T.size(), fin.data()), "read0_many");      // the final claims in one launch and one wait
     absorb(0x12, fin.data(), fin.size());
   }
 
@@ -216,13 +223,13 @@ struct Harness {
   uint32_t layered(std::vector<std::vector<sbn_table*>>& circ, std::vector<sbn_table*>* dotp) {
     uint32_t rounds = 0;
     const size_t nc = circ.size(), nl = circ[0].size();
+    std::vector<sbn_table*> views;                                        // the halves are views (no memory of their own): dropped together at the end
     for (size_t lay = nl; lay-- > 0;) {
       p_layers++;
       std::vector<sbn_table*> A(nc), B(nc);
-      for (size_t i = 0; i < nc; i++) chk(sbn_table_halves(ctx, circ[i][lay], &A[i], &B[i]), "table_halves");
+      for (size_t i = 0; i < nc; i++) { chk(sbn_table_halves(ctx, circ[i][lay], &A[i], &B[i]), "table_halves"); views.push_back(A[i]); views.push_back(B[i]); }
       const size_t half = sbn_table_len(A[0]); size_t k = 0; while (((size_t)1 << k) < half) k++;
       const std::vector<uint8_t> rand = cvec(k);                      // stands in for the accumulated `rand` (product_tree.rs:271)
-      sbn_table* C = nullptr; chk(sbn_eq_evals(ctx, rand.data(), k, &C), "eq_evals C");
       std::vector<sbn_table*> As, Bs, Cs;
       if (lay == 0 && dotp) { const size_t ns = dotp->size() / 3; for (size_t j = 0; j < ns; j++) { As.push_back((*dotp)[j]); Bs.push_back((*dotp)[ns + j]); Cs.push_back((*dotp)[2 * ns + j]); } }
       const size_t ninst = nc + As.size();
@@ -230,8 +237,9 @@ struct Harness {
       if (half >= 2) {
         uint8_t ev[96];
         if (p->stateful_sumcheck) {
+          // poly_C_par = EqPolynomial::new(rand).evals() (product_tree.rs:267-275) is built inside the call: one ABI call opens the layer
           sbn_sumcheck* st = nullptr;
-          chk(sbn_sumcheck_begin(ctx, A.data(), B.data(), C, nc, As.data(), Bs.data(), Cs.data(), As.size(), coeffs.data(), ev, &st), "sumcheck_begin");
+          chk(sbn_sumcheck_begin_eq(ctx, A.data(), B.data(), nc, rand.data(), k, As.data(), Bs.data(), Cs.data(), As.size(), coeffs.data(), ev, &st), "sumcheck_begin_eq");
           for (size_t n = half; n >= 2; n /= 2) {
             absorb(0x20, ev, 96); uint8_t r[32]; challenge(r); rounds++;
             chk(sbn_sumcheck_round(ctx, st, r, ev), "sumcheck_round");
@@ -241,6 +249,7 @@ struct Harness {
           sbn_sumcheck_free(ctx, st);
         } else {
           // the per-instance calls: count x (e0, e2, e3) back per round, combined with coeffs here (sumcheck.rs:269-271)
+          sbn_table* C = nullptr; chk(sbn_eq_evals(ctx, rand.data(), k, &C), "eq_evals C");
           std::vector<sbn_table*> a = A, b = B, c(nc, C);
           a.insert(a.end(), As.begin(), As.end()); b.insert(b.end(), Bs.begin(), Bs.end()); c.insert(c.end(), Cs.begin(), Cs.end());
           std::vector<uint8_t> evs(96 * ninst);
@@ -259,11 +268,11 @@ struct Harness {
           std::vector<uint8_t> fin(32 * all.size());
           for (size_t i = 0; i < all.size(); i++) chk(sbn_table_read0(ctx, all[i], fin.data() + 32 * i), "read0");
           absorb(0x21, fin.data(), fin.size());
+          sbn_table_free(ctx, C);
         }
       }
-      for (size_t i = 0; i < nc; i++) { sbn_table_free(ctx, A[i]); sbn_table_free(ctx, B[i]); }
-      sbn_table_free(ctx, C);
     }
+    for (sbn_table* v : views) sbn_table_free(ctx, v);
     return rounds;
   }
 
@@ -295,6 +304,7 @@ struct Harness {
     memset(h, 0, 32); trace_len = 0; p_rounds_bullet = p_rounds_ops = p_rounds_mem = p_layers = 0;
     for (int i = 0; i < ST_COUNT; i++) ms[i] = 0;
     sbn_table* z = synth_table(ncons, 1);
+    marker(2);                                                            // pass start
     {   // the first commit on a generator set builds its window table: setup
       std::vector<uint8_t> o(64 << wl); chk(sbn_commit_table(ctx, gens_w, z, nullptr, (size_t)1 << wl, (size_t)1 << wr, o.data(), nullptr), "warm commit");
     }
@@ -403,6 +413,7 @@ struct Harness {
     for (void* d : d_addr) sbn_dev_free(ctx, d);
     for (void* d : d_rts) sbn_dev_free(ctx, d);
     for (void* d : d_ats) sbn_dev_free(ctx, d);
+    if (d_scratch) { sbn_dev_free(ctx, d_scratch); d_scratch = nullptr; scratch_bytes = 0; }
     if (gens_o != gens_d) sbn_bases_free(ctx, gens_o);
     sbn_bases_free(ctx, gens_m); sbn_bases_free(ctx, gens_d); sbn_bases_free(ctx, gens_w);
   }

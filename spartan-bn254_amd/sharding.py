@@ -18,6 +18,17 @@ The functions take `torch.distributed` process groups; on a GPU box the backend 
 from . import binding
 
 
+# collectives issued through this module since import (bench.py reports them: evidence that the RCCL path ran, and how often)
+STATS = {"all_gather_calls": 0, "all_gather_bytes_per_rank": 0, "device_tensors": 0}
+
+
+def _count(t):
+    STATS["all_gather_calls"] += 1
+    STATS["all_gather_bytes_per_rank"] += int(t.numel())
+    if t.is_cuda:
+        STATS["device_tensors"] += 1
+
+
 def shard_range(n, rank, world):
     """contiguous base-point range [lo, hi) of rank `rank` (sizes differ by at most one)"""
     q, r = divmod(n, world)
@@ -39,6 +50,7 @@ def allgather_fold(partial_xy, group=None, device=None):
     if device is not None:
         t = t.to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
+    _count(t)
     dist.all_gather(outs, t, group=group)
     allxy = b"".join(bytes(o.cpu().numpy().tobytes()) for o in outs)
     return binding.g1_sum(allxy)
@@ -55,6 +67,7 @@ def gather_rows(rows_xy, L, rank, world, group=None, device=None):
     if device is not None:
         t = t.to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
+    _count(t)
     dist.all_gather(outs, t, group=group)
     full = bytearray(L * 64)
     for r, o in enumerate(outs):
@@ -95,6 +108,7 @@ def allgather_bytes(local, group=None, device=None):
     if device is not None:
         t = t.to(device)
     outs = [torch.empty_like(t) for _ in range(world)]
+    _count(t)
     dist.all_gather(outs, t, group=group)
     return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 

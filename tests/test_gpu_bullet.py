@@ -11,27 +11,32 @@ def _inv(pr, ub):
     return pr.scalar_to_bytes(pow(pr.scalar_from_bytes(ub), pr.R - 2, pr.R))
 
 
-def _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us):
+def _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=False):
+    """fused = False: sbn_bullet_cross + sbn_bullet_fold per round; True: one sbn_bullet_fold_cross per challenge (the prover's call sequence)"""
     n = len(a) // 32
     G = ctx.bases_upload(G_xy, H_xy)
     ta, tb = ctx.table_upload(a), ctx.table_upload(b)
     st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, blind)
     ta.free(); tb.free()                                   # the state holds its own copies (bullet.rs:50-52)
-    Ls, Rs = [], []
+    Ls, Rs, dots = [], [], []
     blind_hat = pr.scalar_from_bytes(blind)
     rnd = 0
+    nxt = None
     while n > 1:
         bl, br = blinds_vec[64 * rnd:64 * rnd + 32], blinds_vec[64 * rnd + 32:64 * rnd + 64]
-        L, _, Rp, _, cL, cR = ctx.bullet_cross(st, bl, br)
-        Ls.append(L); Rs.append(Rp)
+        L, _, Rp, _, cL, cR = nxt if nxt is not None else ctx.bullet_cross(st, bl, br)
+        Ls.append(L); Rs.append(Rp); dots.append(cL + cR)
         u = us[32 * rnd:32 * rnd + 32]; ui = _inv(pr, u)
-        ctx.bullet_fold(st, u, ui)
+        if fused and n >= 4:
+            nxt = ctx.bullet_fold_cross(st, u, ui, blinds_vec[64 * (rnd + 1):64 * (rnd + 1) + 32], blinds_vec[64 * (rnd + 1) + 32:64 * (rnd + 1) + 64])
+        else:
+            ctx.bullet_fold(st, u, ui); nxt = None
         uv, uiv = pr.scalar_from_bytes(u), pr.scalar_from_bytes(ui)
         blind_hat = (uv * uv * pr.scalar_from_bytes(bl) + blind_hat + uiv * uiv * pr.scalar_from_bytes(br)) % pr.R   # bullet.rs:108 (host side)
         n //= 2; rnd += 1
         assert len(st) == n
     a_hat, b_hat, g_hat = ctx.bullet_finish(st)
-    out = dict(L=b"".join(Ls), R=b"".join(Rs), Gamma=Gamma, a_hat=a_hat, b_hat=b_hat, g_hat=g_hat, blind_hat=pr.scalar_to_bytes(blind_hat))
+    out = dict(L=b"".join(Ls), R=b"".join(Rs), Gamma=Gamma, a_hat=a_hat, b_hat=b_hat, g_hat=g_hat, blind_hat=pr.scalar_to_bytes(blind_hat), dots=b"".join(dots))
     st.free(); G.free()
     return out
 
@@ -50,6 +55,8 @@ def test_bullet_rounds_vs_oracle(ctx, ol, pr, n, label):
     got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
     for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
         assert got[k] == want[k], k
+    fused = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=True)     # one call per challenge: the same values, cross terms included
+    assert fused == got
 
 
 def test_bullet_edge_values(ctx, ol, pr):
@@ -68,6 +75,7 @@ def test_bullet_edge_values(ctx, ol, pr):
     got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
     for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
         assert got[k] == want[k], k
+    assert _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=True) == got
 
 
 def test_bullet_optional_terms(ctx, ol, pr):
@@ -109,10 +117,14 @@ def test_bullet_errors(ctx, sbn, ol, pr):
     with pytest.raises(sbn.SbnError):
         ctx.bullet_cross(st, bad, None)
     with pytest.raises(sbn.SbnError):
+        ctx.bullet_fold_cross(st, bad, bad)                # non-canonical challenge
+    with pytest.raises(sbn.SbnError):
         ctx.bullet_finish(st)                             # bullet.rs:114-116: length must be 1
     one = pr.scalar_to_bytes(1)
-    for _ in range(3):
-        ctx.bullet_fold(st, one, one)
+    ctx.bullet_fold_cross(st, one, one); ctx.bullet_fold(st, one, one)          # 8 -> 4 -> 2
+    with pytest.raises(sbn.SbnError):
+        ctx.bullet_fold_cross(st, one, one)                # length 2: the last fold leaves no cross terms
+    ctx.bullet_fold(st, one, one)
     with pytest.raises(sbn.SbnError):
         ctx.bullet_cross(st)                              # nothing left to fold
     ctx.bullet_finish(st)
@@ -132,7 +144,10 @@ def test_bullet_full_size_verifier_relation(ctx, ol, pr):
     Q_xy = pr.point_to_xy(pr.mul((1, 2), 0xABCDEF))
     a, b = rand_scalars(n, 11), rand_scalars(n, 12)
     blind = rand_scalars(1, 13); blinds_vec = rand_scalars(2 * lg, 14); us = rand_scalars(lg, 15)
-    got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+    got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=True)       # the prover's call sequence: one call per challenge
+    assert got == _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)           # ... and the separate cross / fold calls
+    h0 = n // 2
+    assert got["dots"][:64] == ol.fr_dot(a[:32 * h0], b[32 * h0:]) + ol.fr_dot(a[32 * h0:], b[:32 * h0])
     R = pr.R
     u = [pr.scalar_from_bytes(us[32 * i:32 * i + 32]) for i in range(lg)]
     ui = [pow(x, R - 2, R) for x in u]
@@ -167,9 +182,11 @@ def test_bullet_fuzz_sizes(ctx, ol, pr):
         a, b = rand_scalars(n, 3000 + lg), rand_scalars(n, 3100 + lg)
         blind = rand_scalars(1, 3200 + lg); blinds_vec = rand_scalars(2 * lg, 3300 + lg); us = rand_scalars(lg, 3400 + lg)
         want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, blinds_vec, us)
-        got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us)
+        got = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=bool(lg & 1))
         for k in ("L", "R", "Gamma", "a_hat", "b_hat", "g_hat", "blind_hat"):
             assert got[k] == want[k], (n, k)
+        got2 = _run_device(ctx, pr, G_xy, H_xy, Q_xy, a, b, blind, blinds_vec, us, fused=not (lg & 1))
+        assert got2 == got, n
 
 
 def test_bullet_golden(ctx, pr):

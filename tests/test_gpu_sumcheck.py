@@ -697,6 +697,39 @@ def test_stateful_sumcheck_modes_agree(ctx, sbn, ol, pr):
         cx.close()
 
 
+@pytest.mark.parametrize("logn,n_par,n_seq", [(1, 2, 0), (5, 3, 1), (10, 12, 6), (16, 4, 2), (18, 12, 0)])
+def test_stateful_sumcheck_begin_eq(ctx, sbn, ol, logn, n_par, n_seq):
+    """sbn_sumcheck_begin_eq: poly_C_par = EqPolynomial::new(rand).evals() (product_tree.rs:267-275) built inside the call == the same
+    sumcheck begun on an uploaded eq table == the oracle, round by round, final claims included (the eq table's own claim among them)"""
+    n = 1 << logn
+    dev, host = _uniform_tables(ctx, 2 * n_par + 3 * n_seq, n, 8800 + logn)
+    Ap, Bp = dev[:n_par], dev[n_par:2 * n_par]
+    o = 2 * n_par
+    As, Bs, Cs = dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:]
+    rand = rand_scalars(logn, 8900 + logn); ch = rand_scalars(logn, 8901 + logn); co = rand_scalars(n_par + n_seq, 8902 + logn)
+    eq_host = ol.eq_evals(rand)
+    Cp = ctx.table_upload(eq_host)
+    runs = []
+    for mode in ("eq", "table"):
+        st, ev = ctx.sumcheck_begin_eq(Ap, Bp, rand, As, Bs, Cs, co) if mode == "eq" else ctx.sumcheck_begin(Ap, Bp, Cp, As, Bs, Cs, co)
+        got = [ev]
+        for j in range(logn):
+            got.append(st.round(ch[32 * j:32 * j + 32]))
+        runs.append((got, st.finish()))
+        st.free()
+    assert runs[0] == runs[1]
+    import numpy as np
+    _, want_comb, want_fin = ol.sc_prove_cubic_batched(host[:n_par], host[n_par:2 * n_par], np.frombuffer(eq_host, dtype=np.uint8), host[o:o + n_seq], host[o + n_seq:o + 2 * n_seq], host[o + 2 * n_seq:], co, ch, 16)
+    for j in range(logn):
+        assert runs[0][0][j] == want_comb[j], f"round {j}"
+    assert runs[0][1] == want_fin
+    with pytest.raises(sbn.SbnError):
+        ctx.sumcheck_begin_eq(Ap, Bp, rand + rand[:32], As, Bs, Cs, co)                     # rand.len() != num_vars (product_tree.rs:268)
+    Cp.free()
+    for t in dev:
+        t.free()
+
+
 def test_stateful_sumcheck_errors(ctx, sbn, pr):
     a, b, c2 = (ctx.table_upload(rand_scalars(8, s)) for s in (1, 2, 3))
     short = ctx.table_upload(rand_scalars(4, 4))

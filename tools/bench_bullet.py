@@ -1,5 +1,6 @@
 """Time BulletReductionProof::prove's device work (nizk/bullet.rs:63-108) at n = 8192 (the derefs opening's right-hand vector):
-13 rounds of sbn_bullet_cross + sbn_bullet_fold, challenges fixed.  Usage: python tools/bench_bullet.py [log_n]"""
+13 rounds, challenges fixed: sbn_bullet_cross once, then one sbn_bullet_fold_cross per challenge (sbn_bullet_fold for the last); BULLET_SEPARATE=1 times
+the round-3 sequence (cross + fold per round) instead.  Usage: python tools/bench_bullet.py [log_n]"""
 import os
 import sys
 import time
@@ -25,18 +26,30 @@ for rep in range(3):
     ctx.sync(); t0 = time.perf_counter(); tc = tf = 0.0
     st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, us[:32])
     tb0 = time.perf_counter() - t0
-    for r in range(lg):
+    if os.environ.get("BULLET_SEPARATE"):
+        for r in range(lg):
+            t1 = time.perf_counter()
+            ctx.bullet_cross(st, bl[64 * r:64 * r + 32], bl[64 * r + 32:64 * r + 64])
+            t2 = time.perf_counter()
+            ctx.bullet_fold(st, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
+            t3 = time.perf_counter()
+            tc += t2 - t1; tf += t3 - t2
+    else:
         t1 = time.perf_counter()
-        ctx.bullet_cross(st, bl[64 * r:64 * r + 32], bl[64 * r + 32:64 * r + 64])
-        t2 = time.perf_counter()
-        ctx.bullet_fold(st, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
-        t3 = time.perf_counter()
-        tc += t2 - t1; tf += t3 - t2
+        ctx.bullet_cross(st, bl[:32], bl[32:64])
+        tc += time.perf_counter() - t1
+        for r in range(lg):
+            t2 = time.perf_counter()
+            if r + 1 < lg:
+                ctx.bullet_fold_cross(st, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32], bl[64 * (r + 1):64 * (r + 1) + 32], bl[64 * (r + 1) + 32:64 * (r + 1) + 64])
+            else:
+                ctx.bullet_fold(st, us[32 * r:32 * r + 32], uis[32 * r:32 * r + 32])
+            tf += time.perf_counter() - t2
     t4 = time.perf_counter()
     ctx.bullet_finish(st)
     te = time.perf_counter() - t4
     dt = time.perf_counter() - t0
-    print(f"n=2^{lg}: {lg} rounds {dt * 1e3:.2f} ms  (begin+Gamma {tb0 * 1e3:.2f}, cross terms {tc * 1e3:.2f}, folds {tf * 1e3:.2f}, finish {te * 1e3:.2f} ms)")
+    print(f"n=2^{lg}: {lg} rounds {dt * 1e3:.2f} ms  (begin+Gamma {tb0 * 1e3:.2f}, first cross terms {tc * 1e3:.2f}, fold+cross calls {tf * 1e3:.2f}, finish {te * 1e3:.2f} ms)")
     st.free(); ta.free(); tb.free()
 G.free()
 # per-kernel view of one cross round (HIP events)

@@ -16,6 +16,6 @@ from spartan_bn254_amd import binding  # noqa: E402
 ctx = sbn.Context(0)
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 lookup = int(os.environ.get("HARNESS_LOOKUP_GB", "200")) << 30
-stages, digest, _, rounds = binding.harness_prove(ctx, 22, 21, 20, stateful=True, lookup_bytes_sat=16 << 30, lookup_bytes_eval=lookup, seed=11, passes=passes)
+stages, digest, _, rounds = binding.harness_prove(ctx, 22, 21, 20, stateful=True, lookup_bytes_sat=16 << 30, lookup_bytes_eval=lookup, seed=11, passes=passes, trace_markers=bool(os.environ.get("HARNESS_MARKERS", "1") != "0"))
 print(json.dumps({"stage_ms": {k: round(v, 3) for k, v in stages.items()}, "rounds": rounds, "digest": digest.hex()[:16]}))
 ctx.close()
