@@ -244,6 +244,11 @@ int sbn_product_circuit(sbn_ctx* ctx, const sbn_table* in, sbn_table** layers, s
  * a product-circuit layer).  Views share t's memory and must be freed before t. */
 int sbn_table_halves(sbn_ctx* ctx, const sbn_table* t, sbn_table** left, sbn_table** right);
 
+/* entries [first, first + len) of t as a view (len a power of two; freed before t): the polynomials DensePolynomial::merge laid end to end
+ * (hyrax.rs:237-247) are slices of the merged table — e.g. Derefs' row_ops_val / col_ops_val inside `comb` (sparse_mlpoly_full.rs:286-297),
+ * which Layers::new hashes again (sparse_mlpoly_full.rs:745-796) */
+int sbn_table_slice(sbn_ctx* ctx, const sbn_table* t, size_t first, size_t len, sbn_table** out);
+
 /* ---- derefs on the device ----
  * MultiSparseMatPolynomialAsDense::deref -> AddrTimestamps::deref_mem (sparse_mlpoly_full.rs:245-257, 275-279) followed by
  * Derefs::new -> DensePolynomial::merge (sparse_mlpoly_full.rs:293-297, hyrax.rs:237-247):

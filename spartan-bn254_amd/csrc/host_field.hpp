@@ -138,6 +138,18 @@ static inline void to_affine_bytes(const Pt& p, uint8_t out[64], int* is_inf_out
   memcpy(out, x.v, 32); memcpy(out + 32, y.v, 32);   // little-endian host
   if (is_inf_out) *is_inf_out = 0;
 }
+// two points with ONE inversion (Montgomery's trick): a bullet round returns L and R together
+static inline void to_affine_bytes2(const Pt& p, const Pt& q, uint8_t outp[64], int* p_inf, uint8_t outq[64], int* q_inf) {
+  if (is_inf(p) || is_inf(q)) { to_affine_bytes(p, outp, p_inf); to_affine_bytes(q, outq, q_inf); return; }
+  const Fq zp = mul(p.ZZ, p.ZZZ), zq = mul(q.ZZ, q.ZZZ);
+  const Fq I = inv(mul(zp, zq));
+  const Fq Ip = mul(I, zq), Iq = mul(I, zp);
+  const Fq xp = from_mont(mul(p.X, mul(Ip, p.ZZZ))), yp = from_mont(mul(p.Y, mul(Ip, p.ZZ)));
+  const Fq xq = from_mont(mul(q.X, mul(Iq, q.ZZZ))), yq = from_mont(mul(q.Y, mul(Iq, q.ZZ)));
+  memcpy(outp, xp.v, 32); memcpy(outp + 32, yp.v, 32); memcpy(outq, xq.v, 32); memcpy(outq + 32, yq.v, 32);
+  if (p_inf) *p_inf = 0;
+  if (q_inf) *q_inf = 0;
+}
 // sum_w 2^(c*w) * S[w], w = 0..W-1 (Horner from the top window)
 static inline Pt combine_windows(const Pt* S, int W, int c) {
   Pt acc = inf();

@@ -322,6 +322,14 @@ def test_network_construction_pieces(ctx, ol, pr):
     left, right = ctx.table_halves(layers[0])
     hl, hrr = hr[:32 * nops // 2], hr[32 * nops // 2:]
     assert ctx.table_download(left) == hl and ctx.table_download(right) == hrr
+    # slices: any power-of-two run of entries as a view (the polynomials merge() laid end to end: Derefs' row / col polys inside comb)
+    for first, ln in ((0, nops), (nops // 4, nops // 4), (nops - 2, 2), (3, 1)):
+        sl = ctx.table_slice(layers[0], first, ln)
+        assert len(sl) == ln and ctx.table_download(sl) == hr[32 * first:32 * (first + ln)]
+        sl.free()
+    for first, ln in ((0, 3), (nops - 1, 2), (nops + 1, 1), (0, 0)):
+        with pytest.raises(Exception):
+            ctx.table_slice(layers[0], first, ln)
     eqr = rand_scalars(5, 8); tC = ctx.eq_evals(eqr); hC = ol.eq_evals(eqr)
     assert ctx.sc_eval_cubic(left, right, tC) == ol.sc_eval_cubic(hl, hrr, hC)
     r = rand_scalars(1, 9)
