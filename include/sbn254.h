@@ -208,6 +208,11 @@ int sbn_table_bound(sbn_ctx* ctx, const sbn_table* Z, const sbn_table* Lvec, sbn
 typedef struct sbn_bullet sbn_bullet;
 int sbn_bullet_begin(sbn_ctx* ctx, const sbn_bases* G, const uint8_t* Q_xy, const sbn_table* a, const sbn_table* b, const uint8_t* blind,
                      uint8_t* Gamma_xy, int* Gamma_is_inf, sbn_bullet** out);
+/* The same with Q = q_scale * Q_base: DotProductProofLog::prove (nizk/mod.rs:478-494) passes Q = gens_1.scale(r).G[0] with r fresh from the
+ * transcript — a new point per proof over a FIXED base.  Given as (Q_base, q_scale) the derived generator set G || Q_base and its lookup
+ * table are built once per generator set, not once per proof; Q_base's column carries c * q_scale.  Same Gamma, L, R, bit for bit. */
+int sbn_bullet_begin_scaled(sbn_ctx* ctx, const sbn_bases* G, const uint8_t* Q_base_xy, const uint8_t q_scale[32], const sbn_table* a, const sbn_table* b,
+                            const uint8_t* blind, uint8_t* Gamma_xy, int* Gamma_is_inf, sbn_bullet** out);
 void sbn_bullet_free(sbn_ctx* ctx, sbn_bullet* st);
 size_t sbn_bullet_len(const sbn_bullet* st);       /* current n (halves per fold) */
 /* One round's cross terms (bullet.rs:72-78), h = n/2:

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sbn_sumcheck_begin", "sbn_sumcheck_begin_eq", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
     "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_commit_rows_dev", "sbn_group_gather_commit", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_begin_scaled", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -592,6 +592,12 @@ class Context:
         """-> (Bullet state, Gamma_xy or None)"""
         st = C.c_void_p(); gm = (C.c_uint8 * 64)() if want_gamma else None; gi = C.c_int(0)
         self._chk(lib().sbn_bullet_begin(self.h, G.h, _ptr(Q_xy), a.h, b.h, _ptr(blind), gm, C.byref(gi), C.byref(st)), "sbn_bullet_begin")
+        return Bullet(self, st), (bytes(gm) if want_gamma else None)
+
+    def bullet_begin_scaled(self, G, Q_base_xy, q_scale, a, b, blind=None, want_gamma=True):
+        """Q = q_scale * Q_base -> (Bullet state, Gamma_xy or None)"""
+        st = C.c_void_p(); gm = (C.c_uint8 * 64)() if want_gamma else None; gi = C.c_int(0)
+        self._chk(lib().sbn_bullet_begin_scaled(self.h, G.h, _ptr(Q_base_xy), _ptr(q_scale), a.h, b.h, _ptr(blind), gm, C.byref(gi), C.byref(st)), "sbn_bullet_begin_scaled")
         return Bullet(self, st), (bytes(gm) if want_gamma else None)
 
     def bullet_cross(self, st, blind_L=None, blind_R=None):

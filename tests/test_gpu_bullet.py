@@ -98,6 +98,41 @@ def test_bullet_optional_terms(ctx, ol, pr):
     st.free(); G.free(); ta.free(); tb.free()
 
 
+@pytest.mark.parametrize("n", [4, 64, 1024])
+def test_bullet_begin_scaled_q(ctx, ol, pr, n):
+    """sbn_bullet_begin_scaled: Q = r * Q_base as DotProductProofLog::prove passes it (nizk/mod.rs:478-494: gens_1.scale(r).G[0], r fresh per proof):
+    Gamma and every round's L, R, c_L, c_R equal the run that is handed the scaled point itself; the derived set of Q_base is built once"""
+    pts, _ = ol.gens_new(n, b"gens_r1cs_eval")
+    G_xy, H_xy = pts[:64 * n], pts[64 * n:]
+    Q_base = pr.point_to_xy(pr.mul((1, 2), 424242))
+    lg = n.bit_length() - 1
+    a, b = rand_scalars(n, 9100 + n), rand_scalars(n, 9200 + n)
+    blind = rand_scalars(1, 9300); blinds_vec = rand_scalars(2 * lg, 9400 + n); us = rand_scalars(lg, 9500 + n)
+    G = ctx.bases_upload(G_xy, H_xy)
+    for k, r in enumerate((rand_scalars(1, 9600 + n), rand_scalars(1, 9601 + n), pr.scalar_to_bytes(1))):       # several proofs over one generator set
+        Q = ol.g1_mul(Q_base, r)
+        want = ol.bullet_prove(G_xy, Q, H_xy, a, b, blind, blinds_vec, us)
+        ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+        st, Gamma = ctx.bullet_begin_scaled(G, Q_base, r, ta, tb, blind)
+        ta.free(); tb.free()
+        assert Gamma == want["Gamma"]
+        m = n; rnd = 0; nxt = None
+        while m > 1:
+            bl, br = blinds_vec[64 * rnd:64 * rnd + 32], blinds_vec[64 * rnd + 32:64 * rnd + 64]
+            L, _, Rp, _, cL, cR = nxt if nxt is not None else ctx.bullet_cross(st, bl, br)
+            assert L == want["L"][64 * rnd:64 * rnd + 64] and Rp == want["R"][64 * rnd:64 * rnd + 64], (k, rnd)
+            u = us[32 * rnd:32 * rnd + 32]; ui = _inv(pr, u)
+            if m >= 4:
+                nxt = ctx.bullet_fold_cross(st, u, ui, blinds_vec[64 * (rnd + 1):64 * (rnd + 1) + 32], blinds_vec[64 * (rnd + 1) + 32:64 * (rnd + 1) + 64])
+            else:
+                ctx.bullet_fold(st, u, ui); nxt = None
+            m //= 2; rnd += 1
+        a_hat, b_hat, g_hat = ctx.bullet_finish(st)
+        assert (a_hat, b_hat, g_hat) == (want["a_hat"], want["b_hat"], want["g_hat"])
+        st.free()
+    G.free()
+
+
 def test_bullet_errors(ctx, sbn, ol, pr):
     pts, _ = ol.gens_new(8, b"e")
     G = ctx.bases_upload(pts[:64 * 8], pts[64 * 8:])
