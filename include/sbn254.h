@@ -239,6 +239,11 @@ int sbn_bullet_finish(sbn_ctx* ctx, sbn_bullet* st, uint8_t a_hat[32], uint8_t b
  * ts_add = 1 gives the write set (read_ts + 1).  val: table of n entries (eval_table or a derefs poly). */
 int sbn_hash_layer(sbn_ctx* ctx, const void* addr_dev, const sbn_table* val, const void* ts_dev, uint32_t ts_add,
                    const uint8_t r_hash[32], const uint8_t r_multiset[32], sbn_table** out);
+/* Two hashed sets over the same (addr, val) in one pass: the read and write sets of one sparse polynomial (ts_a = ts_b = read_ts, adds 0 and 1) or
+ * the init and audit sets of a memory (addr NULL, ts_a NULL, ts_b = audit_ts) — sparse_mlpoly_full.rs:762-790 builds each pair from the same inputs.
+ * out_a / out_b = what two sbn_hash_layer calls with (ts_a, ts_a_add) / (ts_b, ts_b_add) return. */
+int sbn_hash_layer_pair(sbn_ctx* ctx, const void* addr_dev, const sbn_table* val, const void* ts_a_dev, uint32_t ts_a_add, const void* ts_b_dev, uint32_t ts_b_add,
+                        const uint8_t r_hash[32], const uint8_t r_multiset[32], sbn_table** out_a, sbn_table** out_b);
 /* ProductCircuit::compute_layer (product_tree.rs:21-37): the next layer's full vector out[i] = in[i] * in[i + len/2] */
 int sbn_product_layer(sbn_ctx* ctx, const sbn_table* in, sbn_table** out);
 /* ProductCircuit::new (product_tree.rs:39-57): every layer above `in` in one call — layers[0] = compute_layer(in) (len/2 entries),

@@ -121,6 +121,7 @@ extern "C" {
     pub fn sbn_bullet_fold_cross(ctx: *mut sbn_ctx, st: *mut sbn_bullet, u: *const u8, u_inv: *const u8, blind_l: *const u8, blind_r: *const u8, l_xy: *mut u8, l_is_inf: *mut c_int, r_xy: *mut u8, r_is_inf: *mut c_int, c_l: *mut u8, c_r: *mut u8) -> c_int;
     pub fn sbn_bullet_finish(ctx: *mut sbn_ctx, st: *mut sbn_bullet, a_hat: *mut u8, b_hat: *mut u8, g_hat_xy: *mut u8, g_hat_is_inf: *mut c_int) -> c_int;
     pub fn sbn_hash_layer(ctx: *mut sbn_ctx, addr_dev: *const c_void, val: *const sbn_table, ts_dev: *const c_void, ts_add: u32, r_hash: *const u8, r_multiset: *const u8, out: *mut *mut sbn_table) -> c_int;
+    pub fn sbn_hash_layer_pair(ctx: *mut sbn_ctx, addr_dev: *const c_void, val: *const sbn_table, ts_a_dev: *const c_void, ts_a_add: u32, ts_b_dev: *const c_void, ts_b_add: u32, r_hash: *const u8, r_multiset: *const u8, out_a: *mut *mut sbn_table, out_b: *mut *mut sbn_table) -> c_int;
     pub fn sbn_product_layer(ctx: *mut sbn_ctx, input: *const sbn_table, out: *mut *mut sbn_table) -> c_int;
     pub fn sbn_product_circuit(ctx: *mut sbn_ctx, input: *const sbn_table, layers: *mut *mut sbn_table, cap: usize, count: *mut usize) -> c_int;
     pub fn sbn_table_halves(ctx: *mut sbn_ctx, t: *const sbn_table, left: *mut *mut sbn_table, right: *mut *mut sbn_table) -> c_int;

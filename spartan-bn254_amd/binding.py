@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sbn_sumcheck_begin", "sbn_sumcheck_begin_eq", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
     "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_commit_rows_dev", "sbn_group_gather_commit", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_begin_scaled", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_hash_layer_pair", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_begin_scaled", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -534,6 +534,12 @@ class Context:
         ht = C.c_void_p()
         self._chk(lib().sbn_hash_layer(self.h, C.c_void_p(addr_dev_ptr or 0), val.h, C.c_void_p(ts_dev_ptr or 0), C.c_uint32(ts_add), _ptr(r_hash), _ptr(r_multiset), C.byref(ht)), "sbn_hash_layer")
         return Table(self, ht)
+
+    def hash_layer_pair(self, addr_dev_ptr, val, ts_a_ptr, ts_a_add, ts_b_ptr, ts_b_add, r_hash, r_multiset):
+        ha, hb = C.c_void_p(), C.c_void_p()
+        self._chk(lib().sbn_hash_layer_pair(self.h, C.c_void_p(addr_dev_ptr or 0), val.h, C.c_void_p(ts_a_ptr or 0), C.c_uint32(ts_a_add), C.c_void_p(ts_b_ptr or 0), C.c_uint32(ts_b_add),
+                                            _ptr(r_hash), _ptr(r_multiset), C.byref(ha), C.byref(hb)), "sbn_hash_layer_pair")
+        return Table(self, ha), Table(self, hb)
 
     def product_layer(self, t):
         ht = C.c_void_p(); self._chk(lib().sbn_product_layer(self.h, t.h, C.byref(ht)), "sbn_product_layer"); return Table(self, ht)

@@ -83,10 +83,13 @@ __device__ __forceinline__ XYZZ xyzz_dbl(const XYZZ& p) {
 // acc += q (q affine from a table: canonical, possibly infinity); neg => acc -= q.  8M + 2S on the common path, on the UNSIGNED
 // fast path of fp.cuh: every difference carries an inflated multiple of p, so no limb is ever negative; four carry passes.
 // Value ranges (re-established here): X in [0, 5.2p), Y in [0, 3.2p), ZZ, ZZZ in [0, 1.2p); all limbs normalised.
+// The two infinity tests are exact limb tests (18 and 9 ORs) behind ONE-limb filters: limb 0 of a non-zero coordinate is zero once in
+// 2^29, so the full tests run on the rare path only (tools/micro/maddvar.hip: the gather-fed addition 1.18 -> 1.30 x 10^10 /s at 3 waves
+// per SIMD with the tests out of the way).
 __device__ __forceinline__ void xyzz_madd(XYZZ& acc, const Affine& q_in, bool neg) {
-  if (aff_is_inf(q_in)) return;
+  if ((q_in.x.v[0] | q_in.y.v[0]) == 0) { if (aff_is_inf(q_in)) return; }
   const Fq qy = neg ? fe_negb<FqP, 2>(q_in.y) : q_in.y;                    // 2p - y: limbs below 2^30
-  if (xyzz_is_inf(acc)) { acc.X = q_in.x; acc.Y = fe_normu(qy); acc.ZZ = fe_one<FqP>(); acc.ZZZ = acc.ZZ; return; }
+  if (acc.ZZ.v[0] == 0) { if (xyzz_is_inf(acc)) { acc.X = q_in.x; acc.Y = fe_normu(qy); acc.ZZ = fe_one<FqP>(); acc.ZZZ = acc.ZZ; return; } }
   const Fq U2 = fe_mulu(q_in.x, acc.ZZ), S2 = fe_mulu(qy, acc.ZZZ);        // [0, 1.2p)
   const Fq P = fe_normu(fe_subb<FqP, 6, 1>(U2, acc.X));                    // U2 - X + 6p in (0.8p, 7.2p)
   const Fq R = fe_normu(fe_subb<FqP, 4, 1>(S2, acc.Y));                    // S2 - Y + 4p in (0.8p, 5.2p)

@@ -609,6 +609,22 @@ __global__ void __launch_bounds__(256) k_hash_layer(const uint32_t* __restrict__
     fe_store_tab<FrP>(out + 8 * j, fe_add(acc, ntau));           // three products + (r - tau): (-0.3 r, 4.3 r)
   }
 }
+// two hashed sets over the same (addr, val) in one pass — the read and write sets of one sparse polynomial (ts and ts + 1), or the init and audit
+// sets of a memory (no ts and audit_ts): sparse_mlpoly_full.rs:762-790 builds them in separate loops over the same inputs.  val and addr are read
+// once, val * g + addr - tau is shared; per output one more product (ts * g^2).
+__global__ void __launch_bounds__(256) k_hash_layer_pair(const uint32_t* __restrict__ addr, const uint32_t* __restrict__ val, const uint32_t* __restrict__ ts_a, uint32_t add_a,
+                                                         const uint32_t* __restrict__ ts_b, uint32_t add_b, ScScalar g_m, ScScalar g2rr_m, ScScalar ntau_m, size_t n,
+                                                         uint32_t* __restrict__ out_a, uint32_t* __restrict__ out_b) {
+  const Fr g = fr_from_words(g_m), g2rr = fr_from_words(g2rr_m), ntau = fr_from_words(ntau_m);
+  const Fr rr = fe_const_r2<FrP>();
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long av = addr ? addr[j] : (unsigned long long)j;
+    const unsigned long long ta = (unsigned long long)(ts_a ? ts_a[j] : 0u) + add_a, tb = (unsigned long long)(ts_b ? ts_b[j] : 0u) + add_b;
+    const Fr base = fe_add(fe_add(fe_mul(fe_load<FrP>(val + 8 * j), g), fe_mul(rr, fe_from_u64<FrP>(av))), ntau);        // two products + (r - tau)
+    fe_store_tab<FrP>(out_a + 8 * j, fe_add(base, fe_mul(g2rr, fe_from_u64<FrP>(ta))));                                 // (-0.3 r, 4.3 r) as k_hash_layer
+    fe_store_tab<FrP>(out_b + 8 * j, fe_add(base, fe_mul(g2rr, fe_from_u64<FrP>(tb))));
+  }
+}
 __global__ void __launch_bounds__(256) k_product_layer(const uint32_t* __restrict__ in, size_t half, uint32_t* __restrict__ out) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
     fe_store_tab<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
@@ -673,8 +689,18 @@ __global__ void __launch_bounds__(256) k_bound_partial(const uint32_t* __restric
   const size_t j0 = (size_t)blockIdx.y * rows_per_slice, j1 = (j0 + rows_per_slice < L_size) ? j0 + rows_per_slice : L_size;
   Fr acc = fe_zero<FrP>();
   uint32_t cnt = 0;
-  if (col < R_size)
-    for (size_t j = j0 + wv; j < j1; j += 4) fr_acc(acc, fe_mul(fe_load<FrP>(Lv + 8 * j), fe_load<FrP>(Z + 8 * (j * R_size + col))), cnt);
+  if (col < R_size) {
+    // both operands are table values (non-negative, below 2.5 r): the unsigned product; the next row's element is in flight during the
+    // current product (global loads: a flat load would be drained by the next wait, fp.cuh)
+    size_t j = j0 + wv;
+    Fr zn = fe_zero<FrP>(), ln = zn;
+    if (j < j1) { zn = fe_gload<FrP>(Z + 8 * (j * R_size + col)); ln = fe_gload<FrP>(Lv + 8 * j); }
+    for (; j < j1; j += 4) {
+      const Fr z = zn, l = ln;
+      if (j + 4 < j1) { zn = fe_gload<FrP>(Z + 8 * ((j + 4) * R_size + col)); ln = fe_gload<FrP>(Lv + 8 * (j + 4)); }
+      fr_acc(acc, fe_mulu(l, z), cnt);
+    }
+  }
   acc = fe_reduce(acc);
   __shared__ uint32_t sm[4][64][NL];
   for (int k = 0; k < NL; k++) sm[wv][threadIdx.x & 63][k] = acc.v[k];

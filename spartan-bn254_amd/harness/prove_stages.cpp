@@ -237,10 +237,13 @@ struct Harness {
       chk(sbn_eq_evals(ctx, rl.data(), log_l, &Lv), "eq_evals L"); chk(sbn_eq_evals(ctx, rr.data(), log_r, &Rv), "eq_evals R");
       chk(sbn_table_bound(ctx, Z, Lv, &LZ), "table_bound");
       uint8_t zr[32]; chk(sbn_table_dot(ctx, LZ, Rv, zr), "table_dot"); absorb(0x40, zr, 32);            // the claimed evaluation <LZ, R> = Z(r)
-      uint8_t Q[64] = {0}; Q[0] = 1; Q[32] = 2;
+      // DotProductProofLog::prove (nizk/mod.rs:478-494): r from the transcript, Q = r * gens_1.G[0] — a new point per proof over a fixed base,
+      // handed over as (base, scalar) so that the device's derived generator set is per circuit
+      uint8_t Qb[64] = {0}; Qb[0] = 1; Qb[32] = 2;
+      uint8_t rq[32]; challenge(rq);
       uint8_t blind[32]; challenge(blind);
       uint8_t gamma[64]; int ginf = 0;
-      chk(sbn_bullet_begin(ctx, G, Q, LZ, Rv, blind, gamma, &ginf, &st), "bullet_begin"); absorb(0x41, gamma, 64);
+      chk(sbn_bullet_begin_scaled(ctx, G, Qb, rq, LZ, Rv, blind, gamma, &ginf, &st), "bullet_begin_scaled"); absorb(0x41, gamma, 64);
       // bullet.rs:63-108: per round (blinds from the tape), L and R into the transcript, the challenge u, the folds.  One ABI call per
       // challenge: sbn_bullet_fold_cross folds with u and returns the NEXT round's L, R (the blinds of that round are drawn first, as the
       // reference draws them at the top of its loop body, before L and R exist)
@@ -412,17 +415,15 @@ struct Harness {
       Timer t(this, ST_NETWORK);
       for (int side = 0; side < 2; side++) {
         const sbn_table* mem = side ? mem_ry : mem_rx;
-        sbn_table* x = nullptr;
-        chk(sbn_hash_layer(ctx, nullptr, mem, nullptr, 0, g, tau, &x), "hash init"); mem_circ.push_back({x});
-        chk(sbn_hash_layer(ctx, nullptr, mem, d_ats[side], 0, g, tau, &x), "hash audit"); mem_circ.push_back({x});
+        sbn_table *x = nullptr, *y = nullptr;
+        chk(sbn_hash_layer_pair(ctx, nullptr, mem, nullptr, 0, d_ats[side], 0, g, tau, &x, &y), "hash init + audit"); mem_circ.push_back({x}); mem_circ.push_back({y});
         for (int i = 0; i < 3; i++) {
           const int k = 3 * side + i;
           // row_ops_val[i] / col_ops_val[i] (sparse_mlpoly_full.rs:245-257) were gathered for the derefs commitment: they ARE the six
           // slices of `comb` (Derefs::new merges exactly these polynomials, :293-297) — no second gather
           sbn_table* val = nullptr;
           chk(sbn_table_slice(ctx, comb, (size_t)k * nops, nops, &val), "slice val");
-          chk(sbn_hash_layer(ctx, d_addr[k], val, d_rts[k], 0, g, tau, &x), "hash read"); ops_circ.push_back({x});
-          chk(sbn_hash_layer(ctx, d_addr[k], val, d_rts[k], 1, g, tau, &x), "hash write"); ops_circ.push_back({x});
+          chk(sbn_hash_layer_pair(ctx, d_addr[k], val, d_rts[k], 0, d_rts[k], 1, g, tau, &x, &y), "hash read + write"); ops_circ.push_back({x}); ops_circ.push_back({y});
           sbn_table_free(ctx, val);
         }
       }

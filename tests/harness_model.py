@@ -96,7 +96,8 @@ def opening(rp, Z, log_l, log_r, G_xy, H_xy, what):
     n = 1 << log_r
     LZ = ol.bound(Z, hL, 1 << log_l, n)
     rp.absorb(0x40, ol.fr_dot(LZ, hR), what + ": <LZ, R>")
-    Q = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+    Qb = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+    Q = ol.g1_mul(Qb, rp.challenge())                                  # Q = r * gens_1.G[0], r from the transcript (nizk/mod.rs:478-494)
     blind = rp.challenge()
     # the challenges u_i depend on L_i, R_i: walk the rounds with growing prefixes of the challenge list (each call re-derives the
     # earlier rounds; sizes here are small)

@@ -306,6 +306,12 @@ def test_network_construction_pieces(ctx, ol, pr):
     assert ctx.table_download(t_audit) == ol.hash_layer(None, hmem, audit, 0, g, tau)
     assert ctx.table_download(t_read) == ol.hash_layer(addr, hderef, ts, 0, g, tau)
     assert ctx.table_download(t_write) == ol.hash_layer(addr, hderef, ts, 1, g, tau)
+    # the pairs in one pass each (sbn_hash_layer_pair): read + write of one polynomial, init + audit of a memory
+    p_read, p_write = ctx.hash_layer_pair(d_addr, deref, d_ts, 0, d_ts, 1, g, tau)
+    p_init, p_audit = ctx.hash_layer_pair(None, mem, None, 0, d_au, 0, g, tau)
+    for got, want in ((p_read, t_read), (p_write, t_write), (p_init, t_init), (p_audit, t_audit)):
+        assert ctx.table_download(got) == ctx.table_download(want)
+        got.free()
     # product circuit layers of the read set, down to two entries, against the oracle; evaluate() = product of everything
     cur, hcur = t_read, ol.hash_layer(addr, hderef, ts, 0, g, tau)
     layers = [cur]
