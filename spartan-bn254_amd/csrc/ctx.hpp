@@ -12,7 +12,7 @@ struct DevBuf {
 // Experiment overrides of the sumcheck paths (SBN_SC_*: tools/README.md), read ONCE when the context is created — never on a round's path
 // (441 rounds per prove; getenv is not safe against a concurrent setenv).  A test or sweep that wants another setting creates a context.
 struct ScKnobs {
-  bool no_tiny = false, no_mixed = false, no_mixed_eval = false, no_comb = false, no_comb_kernel = false, no_prebind = false, no_stream_mbox = false;
+  bool no_tiny = false, no_mixed = false, no_mixed_eval = false, no_comb = false, no_comb_kernel = false, no_prebind = false, no_stream_mbox = false, no_fuse_c = false;
   size_t comb_grid = 0;              // 0: automatic
   size_t comb_blocks = 512, seq_blocks = 512, comb_eval_blocks_mixed = 768, eval_blocks_mixed = 768, comb_eval_blocks = 1024, eval_blocks = 2048;
   size_t comb_min_q = (size_t)1 << 14, comb_lanes = 262144, single_max = (size_t)1 << 14, grid = 0, block_rounds = 4;
@@ -23,7 +23,7 @@ static ScKnobs sc_knobs_read() {
   auto flag = [](const char* n) { return getenv(n) != nullptr; };
   auto num = [](const char* n, long long lo, size_t* out) { const char* e = getenv(n); if (!e) return false; const long long x = atoll(e); if (x < lo) return false; *out = (size_t)x; return true; };
   k.no_tiny = flag("SBN_SC_NO_TINY"); k.no_mixed = flag("SBN_SC_NO_MIXED"); k.no_mixed_eval = flag("SBN_SC_NO_MIXED_EVAL"); k.no_comb = flag("SBN_SC_NO_COMB");
-  k.no_comb_kernel = flag("SBN_SC_NO_COMB_KERNEL"); k.no_prebind = flag("SBN_SC_NO_PREBIND"); k.no_stream_mbox = flag("SBN_SC_NO_STREAM_MBOX");
+  k.no_comb_kernel = flag("SBN_SC_NO_COMB_KERNEL"); k.no_prebind = flag("SBN_SC_NO_PREBIND"); k.no_stream_mbox = flag("SBN_SC_NO_STREAM_MBOX"); k.no_fuse_c = flag("SBN_SC_NO_FUSE_C");
   num("SBN_SC_COMB_GRID", 1, &k.comb_grid); num("SBN_SC_COMB_BLOCKS", 1, &k.comb_blocks); num("SBN_SC_SEQ_BLOCKS", 1, &k.seq_blocks);
   if (num("SBN_SC_COMB_EVAL_BLOCKS", 1, &k.comb_eval_blocks)) k.comb_eval_blocks_mixed = k.comb_eval_blocks;
   if (num("SBN_SC_EVAL_BLOCKS", 1, &k.eval_blocks)) k.eval_blocks_mixed = k.eval_blocks;

@@ -378,8 +378,12 @@ static int commit_rows_launch(sbn_ctx* c, const sbn_bases* b, const uint32_t* dZ
     if (ri.internal_rows) rowflags = nullptr;          // no classification pass, no flags to clear (a 1-byte fill was a launch of its own)
     else if (R) LAUNCH(c, "k_merge_scalars", k_row_const_flags, (unsigned)L, 256, dZ, dBl, R, rowflags, ri.mont_scalars ? (uint32_t*)nullptr : c->d_bad);
     else HIPCHK(c, hipMemsetAsync(rowflags, 0, L, c->stream));
-    LAUNCH(c, "k_merge_scalars", k_merge_small, (unsigned)((L * (U + 1) + 255) / 256), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG, (const uint8_t*)rowflags, b->hcol, m, ri.mont_scalars ? 1 : 0);
-    if (b->nbig) LAUNCH(c, "k_merge_scalars", k_merge_big, (unsigned)(L * b->nbig), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, m, ri.mont_scalars ? 1 : 0);
+    {
+      const size_t nsmall = (L * (U + 1) + 255) / 256, nbigb = L * (size_t)b->nbig;
+      if (nsmall + nbigb > 0x7fffffffull) return fail(c, SBN_EINVAL, "commit: merge grid too large");
+      LAUNCH(c, "k_merge_scalars", k_merge, (unsigned)(nsmall + nbigb), 256, dZ, dBl, L, R, U, (const uint32_t*)b->d_csr_off, (const uint32_t*)b->d_csr_cols, MERGE_BIG,
+             (const uint32_t*)b->d_big, b->nbig, (const uint8_t*)rowflags, b->hcol, m, ri.mont_scalars ? 1 : 0, (uint32_t)nsmall);
+    }
     if (c->z_consumed) HIPCHK(c, hipEventRecord(c->z_consumed, c->stream));      // Z (and the blinds) are not read after this point
     RowInfo info; info.flags = rowflags; info.skip_zero = dBl == nullptr;      // with blinds a zero row still commits to blind*h
     info.col_value = U; info.col_blind = (dBl && b->hcol <= U) ? (size_t)b->hcol : ~(size_t)0;

@@ -355,8 +355,18 @@ __global__ void __launch_bounds__(1024) k_size_hist(const uint32_t* __restrict__
   __syncthreads();
   for (uint32_t j = threadIdx.x; j <= SEG; j += blockDim.x) if (bins[j]) atomicAdd(&gbins[j], bins[j]);
 }
+// exclusive scan of the SEG + 1 bins by one wave: lane l owns a contiguous run of bins, the runs' totals are scanned with shuffles
+// (one lane walking all bins was a 27 us dependent chain on the critical path of a single MSM)
 __global__ void __launch_bounds__(64) k_size_scan(uint32_t* __restrict__ gbins, uint32_t SEG) {
-  if (threadIdx.x == 0) { uint32_t run = 0; for (uint32_t j = 0; j <= SEG; j++) { const uint32_t v = gbins[j]; gbins[j] = run; run += v; } }
+  const uint32_t n = SEG + 1, per = (n + 63) / 64, lane = threadIdx.x;
+  const uint32_t j0 = lane * per, j1 = (j0 + per < n) ? j0 + per : n;
+  uint32_t sum = 0;
+  for (uint32_t j = j0; j < j1; j++) sum += gbins[j];
+  uint32_t incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
+  uint32_t run = incl - sum;
+  for (uint32_t j = j0; j < j1; j++) { const uint32_t v = gbins[j]; gbins[j] = run; run += v; }
 }
 __global__ void __launch_bounds__(1024) k_size_scatter(const uint32_t* __restrict__ hist, size_t nbuckets, uint32_t SEG, uint32_t* __restrict__ gcur, uint32_t* __restrict__ perm) {
   __shared__ uint32_t bins[ACC_SEG_MAX + 2];
@@ -611,10 +621,10 @@ __global__ void __launch_bounds__(256) k_row_const_flags(const uint32_t* __restr
 }
 // small groups: one lane per (row, merged column).  Column U is the sum-of-all-bases column; hcol = the unique base h maps to
 // (or U+1 when the table has no h).
-__global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
-                                                     const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
-                                                     const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out, int internal) {
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void merge_small_body(size_t bidx, const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                                 const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
+                                                 const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out, int internal) {
+  const size_t t = bidx * blockDim.x + threadIdx.x;
   const size_t W1 = U + 1;
   if (t >= L * W1) return;
   const size_t row = t / W1, u = t - row * W1;
@@ -633,11 +643,11 @@ __global__ void __launch_bounds__(256) k_merge_small(const uint32_t* __restrict_
 }
 // big groups: one block per (row, big group), four scalars in flight per lane (a bullet round merges 2 x 5381 scalars: one wave
 // with one load at a time was a chain of 84 exposed load latencies); constant rows were written by k_merge_small
-__global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
-                                                   const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
-                                                   const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out, int internal) {
+__device__ __forceinline__ void merge_big_body(size_t bidx, const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                               const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols,
+                                               const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t* __restrict__ out, int internal) {
   __shared__ uint32_t sm[4][NL];
-  const size_t row = blockIdx.x / nbig; const uint32_t u = big_list[blockIdx.x % nbig];
+  const size_t row = bidx / nbig; const uint32_t u = big_list[bidx % nbig];
   if (flags && flags[row]) return;
   const uint32_t a = csr_off[u], b = csr_off[u + 1];
   Fr acc = fe_zero<FrP>();
@@ -661,6 +671,15 @@ __global__ void __launch_bounds__(256) k_merge_big(const uint32_t* __restrict__ 
     for (int w = 1; w < 4; w++) { Fr x; for (int k = 0; k < NL; k++) x.v[k] = sm[w][k]; s = fe_add(s, x); }
     if (internal) fe_store_packed<FrP>(out + 8 * (row * (U + 1) + u), fe_from_mont(fe_reduce(s))); else fe_store<FrP>(out + 8 * (row * (U + 1) + u), s);
   }
+}
+// both kinds of merged column in ONE launch: blocks [0, nsmall) walk the (row, column) pairs of the small groups, the rest take one
+// (row, big group) each — a bullet round's merge was two back-to-back launches of 8 + 15 us
+__global__ void __launch_bounds__(256) k_merge(const uint32_t* __restrict__ Z, const uint32_t* __restrict__ blinds, size_t L, size_t R, size_t U,
+                                               const uint32_t* __restrict__ csr_off, const uint32_t* __restrict__ csr_cols, uint32_t big_threshold,
+                                               const uint32_t* __restrict__ big_list, uint32_t nbig, const uint8_t* __restrict__ flags, uint32_t hcol, uint32_t* __restrict__ out, int internal,
+                                               uint32_t nsmall) {
+  if (blockIdx.x < nsmall) merge_small_body(blockIdx.x, Z, blinds, L, R, U, csr_off, csr_cols, big_threshold, flags, hcol, out, internal);
+  else merge_big_body(blockIdx.x - nsmall, Z, blinds, L, R, U, csr_off, csr_cols, big_list, nbig, flags, out, internal);
 }
 
 // Jacobian (X, Y, Z) -> Montgomery affine, one lane per point (x = X/Z^2, y = Y/Z^3); canonical input is converted first

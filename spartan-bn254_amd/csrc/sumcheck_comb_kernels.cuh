@@ -20,14 +20,17 @@
 namespace sbn {
 
 constexpr int SC_COMB_MAX = 16;          // "par" instances one thread walks (the ops proof has 12, the mem proof 4: sparse_mlpoly_full.rs:1380-1415)
-// One group of instances sharing C, in device memory (read with uniform loads).  Three of these are written when a sumcheck
-// begins (ping, pong, and the first bind, which also scales) — nothing is uploaded per round except the first bind's u, v.
+// One group of instances sharing C, in device memory (read with uniform loads).  Every group of a sumcheck — the round-0 sums and one set
+// per planned combined round — is written when the sumcheck begins (one upload); the first bind's u, v are finished on the device
+// (k_sc_first_uv) once its challenge is known.
 struct ScCombGroup {
   const uint32_t* a_src[SC_COMB_MAX];
   const uint32_t* b_src[SC_COMB_MAX];
   uint32_t* a_dst[SC_COMB_MAX];
   uint32_t* b_dst[SC_COMB_MAX];
   const uint32_t* c;                     // bind+eval kernel: the shared C ALREADY bound to this round's challenge (c[i], c[i + q]); eval kernel: C itself
+  const uint32_t* c_src;                 // bind+eval kernel, when not null: the shared C BEFORE this round's bind (4 q entries) — the thread binds its two entries itself
+  uint32_t* c_dst;                       //   ... and (one group per launch: the writer) stores them here; `c` is not read then
   uint32_t n;                            // instances in the group
   uint32_t scale;                        // 1: the A tables are still unscaled: the first bind writes A' = u z0 + v z2 (u = c_i (1 - r), v = c_i r); eval: A' = u A
   uint32_t u[SC_COMB_MAX][8], v[SC_COMB_MAX][8];   // Montgomery form, canonical
@@ -94,6 +97,7 @@ template <bool SCALE>
 __device__ __forceinline__ void sc_comb_bind_eval_body(const ScCombGroup* __restrict__ g, size_t q, const Fr& r, uint32_t* __restrict__ partial, uint32_t* __restrict__ tickets,
                                                        uint32_t* __restrict__ out, uint32_t slot, uint32_t seq, uint32_t bidx, uint32_t nblk) {
   const uint32_t n = g->n;
+  const uint32_t* csrc = g->c_src; uint32_t* cdst = g->c_dst;
   __shared__ ScLdsAcc acc;
   sc_lds_acc_zero(acc);
   uint32_t cnt = 0;
@@ -126,8 +130,19 @@ __device__ __forceinline__ void sc_comb_bind_eval_body(const ScCombGroup* __rest
       const Fr da = fe_normu(fe_subb<FrP, 3, 1>(a.hi, a.lo)), db = fe_normu(fe_subb<FrP, 3, 1>(b.hi, b.lo));
       cols_mac<FrP>(LL, a.lo, b.lo); cols_mac<FrP>(HH, a.hi, b.hi); cols_mac<FrP>(DD, da, db);
     }
-    const Fr cl = fe_gload<FrP>(g->c + 8 * i), ch = fe_gload<FrP>(g->c + 8 * (i + q));
+    // the shared C of this index: either bound ahead of the launch (g->c) or bound HERE from the unbound table (g->c_src: two more
+    // products per index instead of a launch of its own per round); its loads are issued ahead of the three reductions.  Not in the
+    // scaling first bind (SCALE): that variant sits at the register limit (256 VGPRs) and would spill.
+    const bool fuse = !SCALE && csrc != nullptr;
+    ScQuad zc;
+    if (fuse) zc = sc_quad_load<false>(csrc, i, q); else zc = sc_quad_load<true>(g->c, i, q);
+    SC_PIN();
     const ScS S = sc_bracket_points(cols_reduce<FrP>(LL), cols_reduce<FrP>(HH), cols_reduce<FrP>(DD));
+    Fr cl = zc.z0, ch = zc.z1;
+    if (fuse) {
+      cl = sc_bind1(zc.z0, zc.z2, r); ch = sc_bind1(zc.z1, zc.z3, r);
+      if (cdst) { fe_gstore_packed<FrP>(cdst + 8 * i, cl); fe_gstore_packed<FrP>(cdst + 8 * (i + q), ch); }
+    }
     const ScPts pc = sc_points_u(cl, ch);
     sc_lds_acc_add(acc, 0, fe_mulu(S.s0, cl), cnt); sc_lds_acc_add(acc, 1, fe_mulu(S.s2, pc.v2), cnt); sc_lds_acc_add(acc, 2, fe_mulu(S.s3, pc.v3), cnt);
     cnt++;
