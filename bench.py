@@ -152,7 +152,7 @@ def summarize(line):
         if g(hy, "lookup", "lookup_table", "window_bits"):
             h["lookup_window_bits"] = g(hy, "lookup", "lookup_table", "window_bits")
         for k, v in (hy.get("variants") or {}).items():
-            h[k] = v.get("ms_per_step")
+            h[k] = v.get("ms_per_step", "skipped")
         if "error" in hy:
             h["error"] = hy["error"][:80]
         s["hyrax_ms"] = h
@@ -571,7 +571,26 @@ def main():
                                        "sample": f"first {rows} rows of the same matrix: oracle/ per-row Pippenger, threads over rows (hyrax.rs:259-261)",
                                        "one_thread": {"value": round(2 * Rc / t1, 1), "unit": "pairs/s", "cores": 1, "sample": "first 2 rows, 1 thread; the reference publishes 166.2 s for the whole commitment on one M2 Max core (BENCHMARK_RESULTS.md:37-39)"}}
             line_extra["hyrax"] = res
-            hb.free(); del Z, Zl
+            hb.free(); del Zl
+            if world == 1 and args.precompute_gb > 0 and "variants" in res:
+                # the same 8192 DISTINCT bases with THEIR fixed-base lookup table (the reference's set shares 177 GB among 2814 unique points; 8193 distinct points fit
+                # c = 15: 17 windows x 2^14 multiples x 64 B = 146 GB) — what the commitment costs if the reference ever derives distinct generators (group.rs:110-131)
+                try:
+                    torch.cuda.empty_cache()
+                    db = ctx.bases_synthetic(Rc, 0, S0.to_bytes(32, "little"), DSTEP.to_bytes(32, "little"))
+                    dxy = ctx.bases_download(db, 0, Rc)
+                    tb = time.perf_counter(); cdb = ctx.bases_precompute(db, int(args.precompute_gb * (1 << 30))); tpre = time.perf_counter() - tb
+                    o, _ = ctx.commit_rows_dev(db, Z.data_ptr(), 0, L, Rc)
+                    for i in (0, L // 2 + 1, 3 * L // 4 - 1, L - 1):
+                        if o[64 * i:64 * i + 64] != ol.commit(Z.view(L, Rc * 32)[i].cpu().numpy().tobytes(), bytes(32), dxy, G_XY):
+                            raise SystemExit(f"hyrax distinct-bases lookup: row {i} differs from the oracle")
+                    vdt = timer.run(lambda: ctx.commit_rows_dev(db, Z.data_ptr(), 0, L, Rc), 3)
+                    res["variants"]["distinct_bases_lookup"] = {"ms_per_step": round(vdt / 3 * 1e3, 4), "pairs_per_s": round(L * Rc * 3 / vdt, 1), "window_bits": cdb, "method": "lookup",
+                                                                "lookup_table_build_s": round(tpre, 2), "note": f"{Rc} distinct points with their own lookup table", "parity": "sampled rows bit-exact vs the CPU oracle"}
+                    db.free()
+                except sbn.SbnError as e:
+                    res["variants"]["distinct_bases_lookup"] = {"skipped": str(e)}
+            del Z
         except (sbn.SbnError, RuntimeError) as e:
             line_extra["hyrax"] = {"error": str(e)}
         torch.cuda.empty_cache()

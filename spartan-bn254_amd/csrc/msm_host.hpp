@@ -242,13 +242,21 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
   LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
-  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
+  // The combine level of a job with few chunks (a single MSM of ~2^20 points, small commits) is a latency chain on a nearly empty chip: the
+  // quad-cooperative kernel (256 threads per group of 64 chunks, 3.5 instead of 7.6 us per dependent addition) runs it in 0.115 instead of
+  // 0.141 ms at 2^20.  Level 1 stays one wave per chunk: measured with quads (SBN_RED_QUAD=2) 0.35 - 0.38 ms against 0.277 at L = 4 / 8 / 16 —
+  // four times the waves no longer fit the chip in one round, and that outweighs the shorter additions.
+  static const int red_quad_env = [] { const char* e = getenv("SBN_RED_QUAD"); return e ? atoi(e) : -1; }();
+  const bool red_quad = red_quad_env >= 0 ? red_quad_env != 0 : (J.P * (size_t)chunks <= 2048);
+  if (red_quad_env == 2) LAUNCH(c, "k_reduce_l1", k_reduce_l1_quad, (unsigned)(J.P * chunks), 256, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
+  else LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
   int G = chunks, logM = 6 + logL;
   for (;;) {
     int Gout = (G + 63) / 64;
     int final = (Gout == 1);
-    LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    if (red_quad) LAUNCH(c, "k_reduce_combine", k_reduce_combine_quad, (unsigned)(J.P * Gout), 256, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    else LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
     if (final) break;
     std::swap(in, outb); G = Gout; logM += 6;
   }

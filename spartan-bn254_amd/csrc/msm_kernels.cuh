@@ -541,6 +541,90 @@ __global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restric
   }
 }
 
+// ---- the same two reduction levels for the LATENCY regime (few chunks: a single MSM of ~2^20 points, small commits) ----------------
+// One wave per chunk leaves the chip idle and runs a chain of full additions (14 dependent products, 7.6 us each on a lone wave).
+// Here a chunk is a block of 256 threads = 64 QUADS, each quad standing for one lane of the kernels above: every addition is the
+// quad-cooperative one (g1.cuh: 4 dependent products, ~3.5 us), all four lanes of a quad hold the same values, and quads exchange
+// points through LDS (64 x 128 B).  Same sums, same order of operands inside every addition as far as the group law cares (the
+// results are group elements: any order gives the same point).
+__device__ __forceinline__ void quad_lds_put(uint32_t* sm, int q, int role, const XYZZ& v) { if (role == 0) xyzz_store(sm + 32 * q, v); }
+// suffix scan over the 64 quads of the block: v_q <- sum_{q' >= q} v_q'
+__device__ __forceinline__ XYZZ quad_suffix_scan(XYZZ v, int q, int role, uint32_t* sm) {
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    quad_lds_put(sm, q, role, v);
+    __syncthreads();
+    const XYZZ o = (q + d < 64) ? xyzz_load(sm + 32 * (q + d)) : xyzz_inf();
+    __syncthreads();
+    if (q + d < 64) v = xyzz_add_quad(v, o, role);
+  }
+  return v;
+}
+// sum over the 64 quads, returned in quad 0
+__device__ __forceinline__ XYZZ quad_tree_sum(XYZZ v, int q, int role, uint32_t* sm) {
+#pragma unroll 1
+  for (int d = 32; d >= 1; d >>= 1) {
+    quad_lds_put(sm, q, role, v);
+    __syncthreads();
+    const XYZZ o = (q < d) ? xyzz_load(sm + 32 * (q + d)) : xyzz_inf();
+    __syncthreads();
+    if (q < d) v = xyzz_add_quad(v, o, role);
+  }
+  return v;
+}
+__device__ __forceinline__ XYZZ bucket_load_quad(const uint32_t* __restrict__ p, int G, int role) {
+  XYZZ x = xyzz_load(p);
+  for (int g = 1; g < G; g++) x = xyzz_add_quad(x, xyzz_load(p + 32 * g), role);
+  return x;
+}
+__global__ void __launch_bounds__(256) k_reduce_l1_quad(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem, int G) {
+  __shared__ __align__(16) uint32_t sm[64 * 32];
+  const int q = threadIdx.x >> 2, role = threadIdx.x & 3;
+  const size_t chunk = blockIdx.x;
+  if (skip && skip[chunk / chunks_per_problem] == 2) {   // all-zero row: nothing was accumulated
+    if (threadIdx.x == 0) { xyzz_store(out + 64 * chunk, xyzz_inf()); xyzz_store(out + 64 * chunk + 32, xyzz_inf()); }
+    return;
+  }
+  const uint32_t* base = X + 32 * ((chunk * 64 + q) * (size_t)L) * G;
+  XYZZ run = xyzz_inf(), acc = xyzz_inf();
+  for (int i = L - 1; i >= 1; i--) {
+    run = xyzz_add_quad(run, bucket_load_quad(base + 32 * (size_t)i * G, G, role), role);
+    acc = xyzz_add_quad(acc, run, role);
+  }
+  run = xyzz_add_quad(run, bucket_load_quad(base, G, role), role);
+  const XYZZ suf = quad_suffix_scan(run, q, role, sm);       // suf_q = sum_{q' >= q} run_q'
+  XYZZ term = (q >= 1) ? suf : xyzz_inf();                   // sum_{q >= 1} suf_q = sum_q q * run_q
+  term = xyzz_mul_pow2(term, logL);
+  term = xyzz_add_quad(term, acc, role);
+  const XYZZ Wt = quad_tree_sum(term, q, role, sm);
+  if (threadIdx.x == 0) { xyzz_store(out + 64 * chunk, suf); xyzz_store(out + 64 * chunk + 32, Wt); }
+}
+__global__ void __launch_bounds__(256) k_reduce_combine_quad(const uint32_t* __restrict__ in, int G, int Gout, int logM, int final, uint32_t* __restrict__ out) {
+  __shared__ __align__(16) uint32_t sm[64 * 32];
+  const int q = threadIdx.x >> 2, role = threadIdx.x & 3;
+  const size_t prob = blockIdx.x / Gout;
+  const int grp = blockIdx.x % Gout;
+  const int g = grp * 64 + q;
+  XYZZ S = xyzz_inf(), Wt = xyzz_inf();
+  if (g < G) {
+    const uint32_t* p = in + 64 * (prob * (size_t)G + g);
+    S = xyzz_load(p); Wt = xyzz_load(p + 32);
+  }
+  const XYZZ suf = quad_suffix_scan(S, q, role, sm);
+  XYZZ term = (q >= 1) ? suf : xyzz_inf();
+  term = xyzz_mul_pow2(term, logM);
+  term = xyzz_add_quad(term, Wt, role);
+  const XYZZ W2 = quad_tree_sum(term, q, role, sm);
+  if (threadIdx.x == 0) {
+    if (final) {
+      xyzz_store(out + 32 * prob, xyzz_add_inl(W2, suf));
+    } else {
+      uint32_t* o = out + 64 * (prob * (size_t)Gout + grp);
+      xyzz_store(o, suf); xyzz_store(o + 32, W2);
+    }
+  }
+}
+
 // window table for MODE_ROWS: slab w holds 2^(c*w) * P_j for every base j (XYZZ here; k_xyzz_to_affine finishes it).
 // Setup only, once per generator set and window size.
 __global__ void __launch_bounds__(64) k_window_table(const uint32_t* __restrict__ bases /* npts Montgomery affine */, size_t npts, int c, int W, uint32_t* __restrict__ out_xyzz) {
