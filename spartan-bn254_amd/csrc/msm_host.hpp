@@ -167,15 +167,26 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
   if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
   if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
-  // buckets per lane in the reduction: few buckets -> short lane chains and more waves (latency-bound regime); many buckets ->
-  // longer chains amortise the wave-level scan/tree (throughput-bound regime).  Aim for ~2048 waves.
+  // Buckets per lane (L) of the reduction's first level.  A chunk (one wave, 64 lanes x L buckets) costs a chain of about (2 L - 1) + L (LPB - 1) + 10
+  // additions (running sums, the LPB partial sums of a bucket, the wave's scan and tree) and keeps its SIMD's issue slots busy for all of it, so the
+  // level takes ceil(waves / SIMDs) such chains: L is chosen to minimise that — NOT a power of two in general (2^20 points: 17 windows x 2^14 buckets
+  // with L = 4 are 1 088 waves on 1 024 SIMDs, i.e. 64 SIMDs with two chains, 274 us; L = 5 with a ragged last chunk are 884 waves, one chain each).
+  // Many buckets (millions): the chip holds two waves per SIMD and the level is throughput-bound: the power-of-two rule stays.
   int L = 1; while ((size_t)L * 64 * 2048 < NB && L < 16) L <<= 1;
   if (L < 4) L = 4;
   if (L > s.nb / 64) L = s.nb / 64;
   if (L < 1) L = 1;
-  if (const char* el = getenv("SBN_RED_L")) { int v = atoi(el); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0 && v <= s.nb / 64) L = v; }
-  int logL = 0; while ((1 << logL) < L) logL++;
-  const int chunks = s.nb / (64 * L);                     // per problem, >= 1
+  if (NB <= (size_t)64 * 16 * 1024) {
+    double best = 1e300; int bl = L;
+    for (int t = 1; t <= 32 && t * 64 <= std::max(s.nb, 64); t++) {
+      const size_t waves = J.P * (size_t)((s.nb + 64 * t - 1) / (64 * t));
+      const double cost = (double)((waves + 1023) / 1024) * (double)((2 * t - 1) + t * (LPB - 1) + 10);
+      if (cost < best) { best = cost; bl = t; }
+    }
+    L = bl;
+  }
+  if (const char* el = getenv("SBN_RED_L")) { int v = atoi(el); if (v >= 1 && v <= 64) L = v; }
+  const int chunks = (s.nb + 64 * L - 1) / (64 * L);      // per problem, >= 1; the last one may be ragged
   if ((rc = ensure(c, c->red_a, J.P * chunks * 256))) return rc;
   if ((rc = ensure(c, c->red_b, J.P * ((chunks + 63) / 64) * 256))) return rc;
   if ((rc = ensure(c, c->wsum, J.P * 128))) return rc;
@@ -244,21 +255,20 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
   // The combine level of a job with few chunks (a single MSM of ~2^20 points, small commits) is a latency chain on a nearly empty chip: the
   // quad-cooperative kernel (256 threads per group of 64 chunks, 3.5 instead of 7.6 us per dependent addition) runs it in 0.115 instead of
-  // 0.141 ms at 2^20.  Level 1 stays one wave per chunk: measured with quads (SBN_RED_QUAD=2) 0.35 - 0.38 ms against 0.277 at L = 4 / 8 / 16 —
-  // four times the waves no longer fit the chip in one round, and that outweighs the shorter additions.
+  // 0.141 ms at 2^20.  Level 1 stays one wave per chunk: measured with quads 0.35 - 0.38 ms against 0.277 at L = 4 / 8 / 16 (level 1 is SIMD-issue
+  // bound, not a latency chain: four times the waves at 2.3x the instructions only make the queues longer; profiles/r04_reduce_quad_sweep.txt).
   static const int red_quad_env = [] { const char* e = getenv("SBN_RED_QUAD"); return e ? atoi(e) : -1; }();
   const bool red_quad = red_quad_env >= 0 ? red_quad_env != 0 : (J.P * (size_t)chunks <= 2048);
-  if (red_quad_env == 2) LAUNCH(c, "k_reduce_l1", k_reduce_l1_quad, (unsigned)(J.P * chunks), 256, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
-  else LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, logL, (uint32_t*)c->red_a.p, skip, chunks, LPB);
+  LAUNCH(c, "k_reduce_l1", k_reduce_l1, (unsigned)(J.P * chunks), 64, buckets, L, s.nb, (uint32_t*)c->red_a.p, skip, chunks, LPB);
   uint32_t* in = (uint32_t*)c->red_a.p; uint32_t* outb = (uint32_t*)c->red_b.p;
-  int G = chunks, logM = 6 + logL;
+  int G = chunks, k64 = 1;
   for (;;) {
     int Gout = (G + 63) / 64;
     int final = (Gout == 1);
-    if (red_quad) LAUNCH(c, "k_reduce_combine", k_reduce_combine_quad, (unsigned)(J.P * Gout), 256, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
-    else LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, logM, final, final ? (uint32_t*)c->wsum.p : outb);
+    if (red_quad) LAUNCH(c, "k_reduce_combine", k_reduce_combine_quad, (unsigned)(J.P * Gout), 256, in, G, Gout, k64, L, final, final ? (uint32_t*)c->wsum.p : outb);
+    else LAUNCH(c, "k_reduce_combine", k_reduce_combine, (unsigned)(J.P * Gout), 64, in, G, Gout, k64, L, final, final ? (uint32_t*)c->wsum.p : outb);
     if (final) break;
-    std::swap(in, outb); G = Gout; logM += 6;
+    std::swap(in, outb); G = Gout; k64 += 1;
   }
   LAUNCHCHK(c);
   return SBN_OK;

@@ -450,6 +450,19 @@ __device__ __forceinline__ XYZZ xyzz_mul_pow2(XYZZ v, int k) {
   return v;
 }
 
+// k * v for a small positive integer k (binary double-and-add from the top bit)
+__device__ __forceinline__ XYZZ xyzz_mul_small(const XYZZ& v, uint32_t k) {
+  if (k <= 1) return v;
+  int top = 31 - __clz((int)k);
+  XYZZ r = v;
+#pragma unroll 1
+  for (int b = top - 1; b >= 0; b--) {
+    r = xyzz_dbl(r);
+    if ((k >> b) & 1u) r = xyzz_add_inl(r, v);
+  }
+  return r;
+}
+
 // folding the extra partials back into their bucket: a bucket with few of them is finished by one lane (64 buckets per
 // wave), a bucket with many by one whole wave (lane-strided chains, then a wave tree)
 constexpr uint32_t MERGE_LANE_MAX = 12;
@@ -486,37 +499,41 @@ __device__ __forceinline__ XYZZ bucket_load(const uint32_t* __restrict__ p, int 
   for (int g = 1; g < G; g++) x = xyzz_add_inl(x, xyzz_load(p + 32 * g));
   return x;
 }
-__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem, int G) {
+// L: buckets per lane (any value >= 1: the host picks it so that the chunks spread evenly over the SIMDs); nb: buckets per problem; the last chunk of a
+// problem may be ragged (buckets past nb count as the identity).
+__global__ void __launch_bounds__(64) k_reduce_l1(const uint32_t* __restrict__ X, int L, int nb, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem, int G) {
   const int lane = threadIdx.x;
   const size_t chunk = blockIdx.x;
-  if (skip && skip[chunk / chunks_per_problem] == 2) {   // all-zero row: nothing was accumulated
+  const size_t prob = chunk / chunks_per_problem; const int cidx = (int)(chunk % chunks_per_problem);
+  if (skip && skip[prob] == 2) {   // all-zero row: nothing was accumulated
     if (lane == 0) { xyzz_store(out + 64 * chunk, xyzz_inf()); xyzz_store(out + 64 * chunk + 32, xyzz_inf()); }
     return;
   }
-  const uint32_t* base = X + 32 * ((chunk * 64 + lane) * (size_t)L) * G;
+  const int b0 = (cidx * 64 + lane) * L;                       // this lane's first bucket inside the problem
+  const uint32_t* base = X + 32 * (prob * (size_t)nb + b0) * G;
   // lane-sequential running sums over its L buckets: run = sum X_i, acc = sum i*X_i (local i)
   XYZZ run = xyzz_inf(), acc = xyzz_inf();
   for (int i = L - 1; i >= 1; i--) {
-    run = xyzz_add_inl(run, bucket_load(base + 32 * (size_t)i * G, G));
+    if (b0 + i < nb) run = xyzz_add_inl(run, bucket_load(base + 32 * (size_t)i * G, G));
     acc = xyzz_add_inl(acc, run);
   }
-  run = xyzz_add_inl(run, bucket_load(base, G));
+  if (b0 < nb) run = xyzz_add_inl(run, bucket_load(base, G));
   // across lanes: index = lane*L + local  =>  Wt = sum_l acc_l + L * sum_l l * run_l
   XYZZ suf = wave_suffix_scan(run, lane);          // suf_l = sum_{l'>=l} run_l'
   XYZZ S = suf;                                    // lane 0 holds the chunk total
   XYZZ term = (lane >= 1) ? suf : xyzz_inf();      // sum_{l>=1} suf_l = sum_l l*run_l
-  term = xyzz_mul_pow2(term, logL);
+  term = xyzz_mul_small(term, (uint32_t)L);
   term = xyzz_add_inl(term, acc);
   const XYZZ Wt = wave_sum_all(term);              // 7 quad-cooperative additions deep (g1.cuh), every lane gets the sum
   if (lane == 0) { xyzz_store(out + 64 * chunk, S); xyzz_store(out + 64 * chunk + 32, Wt); }
 }
 
 // combine: one wave per group of 64 consecutive chunk results of one problem; lane l holds chunk g0+l, each chunk
-// standing for M = 2^logM buckets.  Produces the {S, Wt} of the 64*M-bucket super-chunk:
+// standing for M = Lb * 64^k64 buckets (Lb: buckets per lane of level 1, any value).  Produces the {S, Wt} of the 64*M-bucket super-chunk:
 //   S' = sum_l S_l ,  Wt' = sum_l Wt_l + M * sum_l l*S_l
 // G = chunks per problem at the input level (lanes past G contribute the identity); Gout = ceil(G/64).
 // When `final` is set (Gout == 1) the wave writes sum_b (b+1) X_b = Wt' + S' as a single point instead.
-__global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restrict__ in, int G, int Gout, int logM, int final, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restrict__ in, int G, int Gout, int k64, int Lb, int final, uint32_t* __restrict__ out) {
   const int lane = threadIdx.x;
   const size_t prob = blockIdx.x / Gout;
   const int grp = blockIdx.x % Gout;
@@ -528,7 +545,7 @@ __global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restric
   }
   XYZZ suf = wave_suffix_scan(S, lane);
   XYZZ term = (lane >= 1) ? suf : xyzz_inf();
-  term = xyzz_mul_pow2(term, logM);
+  term = xyzz_mul_small(xyzz_mul_pow2(term, 6 * k64), (uint32_t)Lb);
   term = xyzz_add_inl(term, Wt);
   const XYZZ W2 = wave_sum_all(term);
   if (lane == 0) {
@@ -541,9 +558,9 @@ __global__ void __launch_bounds__(64) k_reduce_combine(const uint32_t* __restric
   }
 }
 
-// ---- the same two reduction levels for the LATENCY regime (few chunks: a single MSM of ~2^20 points, small commits) ----------------
-// One wave per chunk leaves the chip idle and runs a chain of full additions (14 dependent products, 7.6 us each on a lone wave).
-// Here a chunk is a block of 256 threads = 64 QUADS, each quad standing for one lane of the kernels above: every addition is the
+// ---- the combine level for the LATENCY regime (few chunks: a single MSM of ~2^20 points, small commits) ----------------
+// One wave per group leaves the chip idle and runs a chain of full additions (14 dependent products, 7.6 us each on a lone wave).
+// Here a group is a block of 256 threads = 64 QUADS, each quad standing for one lane of the kernel above: every addition is the
 // quad-cooperative one (g1.cuh: 4 dependent products, ~3.5 us), all four lanes of a quad hold the same values, and quads exchange
 // points through LDS (64 x 128 B).  Same sums, same order of operands inside every addition as far as the group law cares (the
 // results are group elements: any order gives the same point).
@@ -572,34 +589,7 @@ __device__ __forceinline__ XYZZ quad_tree_sum(XYZZ v, int q, int role, uint32_t*
   }
   return v;
 }
-__device__ __forceinline__ XYZZ bucket_load_quad(const uint32_t* __restrict__ p, int G, int role) {
-  XYZZ x = xyzz_load(p);
-  for (int g = 1; g < G; g++) x = xyzz_add_quad(x, xyzz_load(p + 32 * g), role);
-  return x;
-}
-__global__ void __launch_bounds__(256) k_reduce_l1_quad(const uint32_t* __restrict__ X, int L, int logL, uint32_t* __restrict__ out, const uint8_t* __restrict__ skip, int chunks_per_problem, int G) {
-  __shared__ __align__(16) uint32_t sm[64 * 32];
-  const int q = threadIdx.x >> 2, role = threadIdx.x & 3;
-  const size_t chunk = blockIdx.x;
-  if (skip && skip[chunk / chunks_per_problem] == 2) {   // all-zero row: nothing was accumulated
-    if (threadIdx.x == 0) { xyzz_store(out + 64 * chunk, xyzz_inf()); xyzz_store(out + 64 * chunk + 32, xyzz_inf()); }
-    return;
-  }
-  const uint32_t* base = X + 32 * ((chunk * 64 + q) * (size_t)L) * G;
-  XYZZ run = xyzz_inf(), acc = xyzz_inf();
-  for (int i = L - 1; i >= 1; i--) {
-    run = xyzz_add_quad(run, bucket_load_quad(base + 32 * (size_t)i * G, G, role), role);
-    acc = xyzz_add_quad(acc, run, role);
-  }
-  run = xyzz_add_quad(run, bucket_load_quad(base, G, role), role);
-  const XYZZ suf = quad_suffix_scan(run, q, role, sm);       // suf_q = sum_{q' >= q} run_q'
-  XYZZ term = (q >= 1) ? suf : xyzz_inf();                   // sum_{q >= 1} suf_q = sum_q q * run_q
-  term = xyzz_mul_pow2(term, logL);
-  term = xyzz_add_quad(term, acc, role);
-  const XYZZ Wt = quad_tree_sum(term, q, role, sm);
-  if (threadIdx.x == 0) { xyzz_store(out + 64 * chunk, suf); xyzz_store(out + 64 * chunk + 32, Wt); }
-}
-__global__ void __launch_bounds__(256) k_reduce_combine_quad(const uint32_t* __restrict__ in, int G, int Gout, int logM, int final, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_combine_quad(const uint32_t* __restrict__ in, int G, int Gout, int k64, int Lb, int final, uint32_t* __restrict__ out) {
   __shared__ __align__(16) uint32_t sm[64 * 32];
   const int q = threadIdx.x >> 2, role = threadIdx.x & 3;
   const size_t prob = blockIdx.x / Gout;
@@ -612,7 +602,7 @@ __global__ void __launch_bounds__(256) k_reduce_combine_quad(const uint32_t* __r
   }
   const XYZZ suf = quad_suffix_scan(S, q, role, sm);
   XYZZ term = (q >= 1) ? suf : xyzz_inf();
-  term = xyzz_mul_pow2(term, logM);
+  term = xyzz_mul_small(xyzz_mul_pow2(term, 6 * k64), (uint32_t)Lb);
   term = xyzz_add_quad(term, Wt, role);
   const XYZZ W2 = quad_tree_sum(term, q, role, sm);
   if (threadIdx.x == 0) {
