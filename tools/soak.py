@@ -96,7 +96,16 @@ while time.time() < t_end:
         for _ in range(rng.choice([0, 0, 1, 2])):
             i = rng.randrange(n_par + n_seq); co[32 * i:32 * i + 32] = pr.scalar_to_bytes(rng.choice([0, 1, 2, pr.R - 1]))
         co = bytes(co); ch = rand_scalars(logn, sd + 101)
-        st, ev = ctx.sumcheck_begin(dev[:n_par], dev[n_par:2 * n_par], dev[2 * n_par] if n_par else None, dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:], co)
+        if n_par and rng.random() < 0.4:
+            # round 4: poly_C_par = eq(rand) built inside the call (sbn_sumcheck_begin_eq); the oracle gets the same table from the device's sbn_eq_evals
+            rand = rand_scalars(logn, sd + 102)
+            eqt = ctx.eq_evals(rand); host[2 * n_par] = ctx.table_download(eqt); eqt.free()
+            st, ev = ctx.sumcheck_begin_eq(dev[:n_par], dev[n_par:2 * n_par], rand, dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:], co)
+            counts["begin_eq"] = counts.get("begin_eq", 0) + 1
+            host_c_replaced = True
+        else:
+            host_c_replaced = False
+            st, ev = ctx.sumcheck_begin(dev[:n_par], dev[n_par:2 * n_par], dev[2 * n_par] if n_par else None, dev[o:o + n_seq], dev[o + n_seq:o + 2 * n_seq], dev[o + 2 * n_seq:], co)
         got = [ev]
         for j in range(logn):
             ev = st.round(ch[32 * j:32 * j + 32])
@@ -107,24 +116,41 @@ while time.time() < t_end:
         _, want_comb, want_fin = ol.sc_prove_cubic_batched(hn[:n_par], hn[n_par:2 * n_par], hn[2 * n_par] if n_par else None, hn[o:o + n_seq], hn[o + n_seq:o + 2 * n_seq], hn[o + 2 * n_seq:], co, ch, 8)
         assert got == list(want_comb[:logn]), ("stateful rounds", logn, n_par, n_seq, sd)
         assert fin == want_fin, ("stateful finals", logn, n_par, n_seq, sd)
-        assert ctx.table_read0_many(dev) == [x[:32] for x in host], ("stateful left the caller's tables alone", sd)
+        if not host_c_replaced:
+            assert ctx.table_read0_many(dev) == [x[:32] for x in host], ("stateful left the caller's tables alone", sd)
         for t in dev: t.free()
     else:
-        lg = rng.randrange(1, 8); n = 1 << lg
+        lg = rng.choice([1, 2, 3, 4, 5, 6, 7, 7, 10, 11]); n = 1 << lg
         pts, _ = ol.gens_new(n, rng.choice([b"gens_r1cs_eval", b"b%d" % sd]), 8)
         G_xy, H_xy = pts[:64 * n], pts[64 * n:]
         Q_xy = pr.point_to_xy(pr.mul((1, 2), 1 + sd))
         a, b = special(rand_scalars(n, sd), n), special(rand_scalars(n, sd + 1), n)
         blind = rand_scalars(1, sd + 2); bv = rand_scalars(2 * lg, sd + 3); us = rand_scalars(lg, sd + 4)
-        want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, bv, us)
-        G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
-        st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, blind)
+        if rng.random() < 0.5:
+            # round 4: Q = q_scale * Q_base (nizk/mod.rs:478-494) — the oracle is handed the product
+            qs = 1 + rng.randrange(pr.R - 1); Qb_xy = Q_xy
+            Q_xy = pr.point_to_xy(pr.mul((1, 2), (1 + sd) * qs % pr.R))
+            want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, bv, us)
+            G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+            st, Gamma = ctx.bullet_begin_scaled(G, Qb_xy, pr.scalar_to_bytes(qs), ta, tb, blind)
+            counts["begin_scaled"] = counts.get("begin_scaled", 0) + 1
+        else:
+            want = ol.bullet_prove(G_xy, Q_xy, H_xy, a, b, blind, bv, us)
+            G = ctx.bases_upload(G_xy, H_xy); ta, tb = ctx.table_upload(a), ctx.table_upload(b)
+            st, Gamma = ctx.bullet_begin(G, Q_xy, ta, tb, blind)
         assert Gamma == want["Gamma"], ("bullet gamma", n, sd)
+        fused = rng.random() < 0.6
+        inv = lambda u: pr.scalar_to_bytes(pow(pr.scalar_from_bytes(u), pr.R - 2, pr.R))
         for rnd in range(lg):
-            L, _, Rp, _, _, _ = ctx.bullet_cross(st, bv[64 * rnd:64 * rnd + 32], bv[64 * rnd + 32:64 * rnd + 64])
+            bl, br = bv[64 * rnd:64 * rnd + 32], bv[64 * rnd + 32:64 * rnd + 64]
+            if fused and rnd > 0:       # one call per challenge: fold with the previous u, return this round's L, R (sbn_bullet_fold_cross)
+                up = us[32 * (rnd - 1):32 * rnd]
+                L, _, Rp, _, _, _ = ctx.bullet_fold_cross(st, up, inv(up), bl, br)
+            else:
+                L, _, Rp, _, _, _ = ctx.bullet_cross(st, bl, br)
             assert L == want["L"][64 * rnd:64 * rnd + 64] and Rp == want["R"][64 * rnd:64 * rnd + 64], ("bullet round", n, rnd, sd)
             u = us[32 * rnd:32 * rnd + 32]
-            ctx.bullet_fold(st, u, pr.scalar_to_bytes(pow(pr.scalar_from_bytes(u), pr.R - 2, pr.R)))
+            if not fused or rnd == lg - 1: ctx.bullet_fold(st, u, inv(u))
         ah, bh, gh = ctx.bullet_finish(st)
         assert (ah, bh, gh) == (want["a_hat"], want["b_hat"], want["g_hat"]), ("bullet finish", n, sd)
         st.free(); ta.free(); tb.free(); G.free()
