@@ -837,3 +837,26 @@ def test_two_level_sort_matches_one_level(ctx, ctx_sort2, ol, monkeypatch):
     for c_bits in (15, 16):
         monkeypatch.setenv("SBN_MSM_C", str(c_bits))
         assert ctx.msm(sc, pts) == ctx_sort2.msm(sc, pts)
+
+
+@pytest.mark.parametrize("L", [1, 3, 5, 7, 11, 33])
+def test_bucket_reduction_any_buckets_per_lane(ctx, ol, pr, monkeypatch, L):
+    """k_reduce_l1 with L buckets per lane, L not a power of two: the last chunk of a window is ragged (buckets past the end count as
+    the identity), the cross-lane weight is L * lane and the combine levels weigh a chunk with L * 64^k.  Window widths whose bucket
+    counts are one lane-row (c = 7: 64 buckets, every L > 1 leaves most lanes past the end), not a multiple of 64 L, and large (c = 15, two
+    combine levels at small L); plus a shared-bucket-set row commit.  Bit-exact vs the discrete-log identity / the oracle."""
+    monkeypatch.setenv("SBN_RED_L", str(L))
+    for c_bits, n in [(7, 100), (8, 300), (10, 3000), (13, 9000), (15, 40000)]:
+        monkeypatch.setenv("SBN_MSM_C", str(c_bits))
+        sc = rand_scalars(n, 31 * L + c_bits)
+        pts, dl = tiled_bases(ol, n, min(n, 4096), 3 + n)
+        out, inf = ctx.msm(sc, pts)
+        assert ctx.prof_last_job()["c"] == c_bits
+        assert out == expect_from_dlogs(ol, pr, sc, dl) and not inf, (L, c_bits, n)
+    monkeypatch.delenv("SBN_MSM_C")
+    Lr, R = 5, 1000
+    gx, _ = ol.gens_new(R, b"gens_r1cs_sat", 8)
+    Z = rand_scalars(Lr * R, 77 + L); bl = rand_scalars(Lr, 78 + L)
+    b = ctx.bases_upload(gx[:64 * R], gx[64 * R:])
+    assert ctx.commit_rows(b, Z, bl, Lr, R)[0] == ol.commit_rows(Z, bl, Lr, R, gx[:64 * R], gx[64 * R:], 8)
+    b.free()
