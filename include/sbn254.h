@@ -250,6 +250,11 @@ int sbn_product_layer(sbn_ctx* ctx, const sbn_table* in, sbn_table** out);
  * layers[k] = compute_layer(layers[k-1]), down to the single-entry layer whose value is the circuit's product (evaluate(), :59-66).
  * cap = size of the caller's array (log2(len) layers are produced), *count <- number written.  Enqueued only, like sbn_product_layer. */
 int sbn_product_circuit(sbn_ctx* ctx, const sbn_table* in, sbn_table** layers, size_t cap, size_t* count);
+/* n product circuits over tables of ONE length, built together: layers[i * cap + k] = layer k of circuit i, *count <- layers per circuit.
+ * The hashed sets of a sparse-polynomial evaluation proof all get their circuit at the same point (sparse_mlpoly_full.rs:813-823: row / col x
+ * read / write over the operations, init / audit over the memories); one launch per layer serves all of them — below ~2^15 entries a layer's
+ * launch costs more than its arithmetic.  Same values as n sbn_product_circuit calls. */
+int sbn_product_circuit_many(sbn_ctx* ctx, const sbn_table* const* ins, size_t n, sbn_table** layers, size_t cap, size_t* count);
 /* DensePolynomial::split(len/2) (hyrax.rs:186-192) as views: left = first half, right = second half of `t` (the A and B tables of
  * a product-circuit layer).  Views share t's memory and must be freed before t. */
 int sbn_table_halves(sbn_ctx* ctx, const sbn_table* t, sbn_table** left, sbn_table** right);

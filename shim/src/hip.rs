@@ -124,6 +124,7 @@ extern "C" {
     pub fn sbn_hash_layer_pair(ctx: *mut sbn_ctx, addr_dev: *const c_void, val: *const sbn_table, ts_a_dev: *const c_void, ts_a_add: u32, ts_b_dev: *const c_void, ts_b_add: u32, r_hash: *const u8, r_multiset: *const u8, out_a: *mut *mut sbn_table, out_b: *mut *mut sbn_table) -> c_int;
     pub fn sbn_product_layer(ctx: *mut sbn_ctx, input: *const sbn_table, out: *mut *mut sbn_table) -> c_int;
     pub fn sbn_product_circuit(ctx: *mut sbn_ctx, input: *const sbn_table, layers: *mut *mut sbn_table, cap: usize, count: *mut usize) -> c_int;
+    pub fn sbn_product_circuit_many(ctx: *mut sbn_ctx, ins: *const *const sbn_table, n: usize, layers: *mut *mut sbn_table, cap: usize, count: *mut usize) -> c_int;
     pub fn sbn_table_halves(ctx: *mut sbn_ctx, t: *const sbn_table, left: *mut *mut sbn_table, right: *mut *mut sbn_table) -> c_int;
     pub fn sbn_table_slice(ctx: *mut sbn_ctx, t: *const sbn_table, first: usize, len: usize, out: *mut *mut sbn_table) -> c_int;
     pub fn sbn_gather_merge(ctx: *mut sbn_ctx, mem: *const *const sbn_table, addr_dev: *const *const c_void, count: usize, n: usize, out: *mut *mut sbn_table) -> c_int;

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sbn_sumcheck_begin", "sbn_sumcheck_begin_eq", "sbn_sumcheck_round", "sbn_sumcheck_len", "sbn_sumcheck_finish", "sbn_sumcheck_free",
     "sbn_group_create", "sbn_group_destroy", "sbn_group_size", "sbn_group_ctx", "sbn_group_last_error", "sbn_group_bases_upload", "sbn_group_gens_new", "sbn_group_bases_precompute",
     "sbn_group_bases_free", "sbn_group_commit_rows", "sbn_group_commit_rows_dev", "sbn_group_gather_commit", "sbn_group_msm", "sbn_group_bases_upload_ranges", "sbn_group_bases_synthetic_ranges", "sbn_group_range", "sbn_group_msm_bases", "sbn_group_msm_bases_dev",
-    "sbn_eq_evals", "sbn_hash_layer", "sbn_hash_layer_pair", "sbn_product_layer", "sbn_product_circuit", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_begin_scaled", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
+    "sbn_eq_evals", "sbn_hash_layer", "sbn_hash_layer_pair", "sbn_product_layer", "sbn_product_circuit", "sbn_product_circuit_many", "sbn_table_halves", "sbn_table_slice", "sbn_table_dot", "sbn_table_evaluate", "sbn_table_evaluate_many", "sbn_table_bound", "sbn_gather_merge", "sbn_gather_merge_rows", "sbn_commit_table", "sbn_bullet_begin", "sbn_bullet_begin_scaled", "sbn_bullet_free", "sbn_bullet_len", "sbn_bullet_cross", "sbn_bullet_fold_cross", "sbn_bullet_fold", "sbn_bullet_finish", "sbn_prof_enable", "sbn_prof_reset", "sbn_prof_count", "sbn_prof_get", "sbn_prof_last_job",
 ]
 
 
@@ -550,6 +550,13 @@ class Context:
         arr = (C.c_void_p * cap)(); cnt = C.c_size_t(0)
         self._chk(lib().sbn_product_circuit(self.h, t.h, arr, C.c_size_t(cap), C.byref(cnt)), "sbn_product_circuit")
         return [Table(self, C.c_void_p(arr[i])) for i in range(cnt.value)]
+
+    def product_circuit_many(self, ts):
+        """the circuits of several tables of one length, one launch per layer for all -> [[layers of ts[0]], [layers of ts[1]], ...]"""
+        n = len(ts); cap = max(1, len(ts[0]).bit_length())
+        ins = (C.c_void_p * n)(*[t.h for t in ts]); arr = (C.c_void_p * (n * cap))(); cnt = C.c_size_t(0)
+        self._chk(lib().sbn_product_circuit_many(self.h, ins, C.c_size_t(n), arr, C.c_size_t(cap), C.byref(cnt)), "sbn_product_circuit_many")
+        return [[Table(self, C.c_void_p(arr[i * cap + k])) for k in range(cnt.value)] for i in range(n)]
 
     def table_halves(self, t):
         l, r = C.c_void_p(), C.c_void_p()

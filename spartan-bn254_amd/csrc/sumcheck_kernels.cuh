@@ -647,6 +647,39 @@ __global__ void __launch_bounds__(1024) k_product_tail(const uint32_t* __restric
     if (half == 1) break;
   }
 }
+// The same two kernels for up to PC_MANY_MAX circuits of one size at once (blockIdx.y = circuit): the 16 product circuits of a prove (12 over the
+// operations' hashed sets, 4 over the memories') are built at the same point (sparse_mlpoly_full.rs:813-823), and below ~2^15 entries a layer's launch
+// costs more than its arithmetic — one launch per layer for all circuits instead of one per layer and circuit.
+constexpr int PC_MANY_MAX = 16;
+struct ProductLayerPack { const uint32_t* in[PC_MANY_MAX]; uint32_t* out[PC_MANY_MAX]; };
+__global__ void __launch_bounds__(256) k_product_layer_many(ProductLayerPack pk, size_t half) {
+  const uint32_t* in = nullptr; uint32_t* out = nullptr;
+#pragma unroll
+  for (int i = 0; i < PC_MANY_MAX; i++) if (i == (int)blockIdx.y) { in = pk.in[i]; out = pk.out[i]; }
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x)
+    fe_store_tab<FrP>(out + 8 * i, fe_mul(fe_load<FrP>(in + 8 * i), fe_load<FrP>(in + 8 * (i + half))));
+}
+// tails: circuit blockIdx.x, layers out[circuit][k] (uniform selects over the kernel-argument block: a dynamic index would move it to scratch)
+struct ProductTailPack { const uint32_t* in[PC_MANY_MAX]; uint32_t* out[PC_MANY_MAX][PT_TAIL_MAX]; };
+__global__ void __launch_bounds__(1024) k_product_tail_many(ProductTailPack pk, size_t len) {
+  const uint32_t* src = nullptr;
+#pragma unroll
+  for (int i = 0; i < PC_MANY_MAX; i++) if (i == (int)blockIdx.x) src = pk.in[i];
+  int k = 0;
+  for (size_t half = len / 2; half >= 1; half >>= 1, k++) {
+    uint32_t* dst = nullptr;
+#pragma unroll
+    for (int i = 0; i < PC_MANY_MAX; i++) {
+#pragma unroll
+      for (int j = 0; j < PT_TAIL_MAX; j++) if (i == (int)blockIdx.x && j == k) dst = pk.out[i][j];
+    }
+    for (size_t i = threadIdx.x; i < half; i += blockDim.x) fe_store_tab<FrP>(dst + 8 * i, fe_mul(fe_load<FrP>(src + 8 * i), fe_load<FrP>(src + 8 * (i + half))));
+    __threadfence_block();
+    __syncthreads();
+    src = dst;
+    if (half == 1) break;
+  }
+}
 // one running sum per thread -> the block's sum in the 3-slot layout of k_sc_finish (slots 1, 2 zero)
 __device__ __forceinline__ void sc_block_sum1_store(Fr acc, uint32_t* __restrict__ o) {
   __shared__ uint32_t sm[4][NL];

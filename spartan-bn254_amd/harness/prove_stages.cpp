@@ -428,11 +428,14 @@ struct Harness {
         }
       }
       std::vector<sbn_table*> tops;                                        // all 16 circuits are enqueued, then their products come back in one wait
-      for (auto* grp : {&ops_circ, &mem_circ}) for (auto& c : *grp) {
-        sbn_table* layers[48]; size_t cnt = 0;
-        chk(sbn_product_circuit(ctx, c[0], layers, 48, &cnt), "product_circuit");
-        for (size_t j = 0; j + 1 < cnt; j++) c.push_back(layers[j]);
-        tops.push_back(layers[cnt - 1]);                                  // the single-entry layer is the product itself (ProductCircuit::evaluate)
+      for (auto* grp : {&ops_circ, &mem_circ}) {                          // the circuits of one kind have one length: one launch per layer for all of them
+        std::vector<const sbn_table*> ins; for (auto& c : *grp) ins.push_back(c[0]);
+        std::vector<sbn_table*> layers(ins.size() * 48, nullptr); size_t cnt = 0;
+        chk(sbn_product_circuit_many(ctx, ins.data(), ins.size(), layers.data(), 48, &cnt), "product_circuit_many");
+        for (size_t i = 0; i < ins.size(); i++) {
+          for (size_t j = 0; j + 1 < cnt; j++) (*grp)[i].push_back(layers[i * 48 + j]);
+          tops.push_back(layers[i * 48 + cnt - 1]);                       // the single-entry layer is the product itself (ProductCircuit::evaluate)
+        }
       }
       std::vector<uint8_t> prods(32 * tops.size());
       chk(sbn_table_read0_many(ctx, tops.data(), tops.size(), prods.data()), "read0 products");

@@ -495,6 +495,33 @@ def test_product_circuit_one_call(ctx, ol, sbn, logn):
     one.free(); t.free()
 
 
+@pytest.mark.parametrize("logn,count", [(1, 3), (5, 16), (11, 4), (12, 12), (14, 17)])   # 17 circuits: two batches; 2^12, 2^14: streaming layers + the tail
+def test_product_circuit_many(ctx, ol, sbn, logn, count):
+    """sbn_product_circuit_many: the circuits of several tables of one length built together (Layers::new, sparse_mlpoly_full.rs:813-823)
+    == one sbn_product_circuit per table == the oracle's repeated compute_layer"""
+    n = 1 << logn
+    vs = [rand_scalars(n, 4100 + 7 * logn + i) for i in range(count)]
+    ts = [ctx.table_upload(v) for v in vs]
+    circ = ctx.product_circuit_many(ts)
+    assert len(circ) == count
+    for i, layers in enumerate(circ):
+        assert [len(x) for x in layers] == [n >> (k + 1) for k in range(logn)]
+        w = vs[i]
+        for x in layers:
+            w = ol.product_layer(w)
+            assert ctx.table_download(x) == w, (i, len(x))
+    single = ctx.product_circuit(ts[-1])
+    assert [ctx.table_download(x) for x in single] == [ctx.table_download(x) for x in circ[-1]]
+    for x in single + [x for layers in circ for x in layers]:
+        x.free()
+    other = ctx.table_upload(rand_scalars(2 * n, 9))
+    with pytest.raises(sbn.SbnError):
+        ctx.product_circuit_many([ts[0], other])          # one length per call
+    other.free()
+    for t in ts:
+        t.free()
+
+
 def test_reference_product_tree_known_answers(ctx, pr):
     """the reference's own unit-test values (product_tree.rs:544-590): ProductCircuit over [2, 3, 5, 7] evaluates to 210;
     DotProductCircuit([1,2,3,4], [5,6,7,8], weights 1) evaluates to 70"""
