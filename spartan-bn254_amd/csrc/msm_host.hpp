@@ -37,6 +37,11 @@ static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, siz
     }
     return make_shape(bcl);
   }
+  // One MSM between the latency regime and 2^20 terms: c = 15 (254 = 16 x 15 + 14: the top window is as wide as the others).  The product count below
+  // would pick windows whose top digit has 2 - 7 bits (c = 8, 12, 13): their handful of top buckets take n / 2^tb points each, a chain of segments and
+  // merges that runs AFTER the main pass — measured (tools/sweep_small_msm_c.py, profiles/r04_small_msm_window_sweep.txt) at 2^16 / 2^17 / 2^18:
+  // 880 / 1055 / 1209 us with c = 12 / 13 / 13 against 610 / 769 / 1129 with c = 15; 15 is also the measured optimum at 2^15 and 2^19.
+  if (!shared_bucket_set && terms < ((size_t)1 << 20) && cmax >= 15) return make_shape(15);
   double best = 1e300; int bc = 7;
   // cmax: one sort block keeps all 2^(c-1) counters of a problem in LDS; beyond that every block re-reads its digits once
   // per counter range (measured at 2^26, c = 20: sort 82 ms vs accumulate 74 ms), which costs more than the 13 -> 16 windows;
