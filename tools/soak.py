@@ -31,8 +31,11 @@ def special(b, n):
 
 
 case = 0
+t_note = time.time() + 60
 while time.time() < t_end:
     case += 1
+    if time.time() > t_note:          # a line a minute: a silent GPU command is taken to be hung
+        print("soak: %d cases so far" % case, counts, flush=True); t_note = time.time() + 60
     kind = rng.choice(["msm", "commit", "commit", "sumcheck", "stateful", "stateful", "bullet"])
     sd = rng.randrange(1 << 30)
     if kind == "msm":
