@@ -66,12 +66,14 @@ static bool sort2_set_lds() {
   const int bytes = (int)s2_scatter_lds_bytes(S2_P_MAX);
   if (hipFuncSetAttribute((const void*)k_s2_place<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_place_lds_bytes<8>(S2_LO_LOG_MAX)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
   if (hipFuncSetAttribute((const void*)k_s2_place<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s2_place_lds_bytes<16>(S2_LO_LOG_MAX)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
-#define X(C) if (hipFuncSetAttribute((const void*)k_s2_scatter<C>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+#define X(C) if (hipFuncSetAttribute((const void*)k_s2_scatter<C, S2_SPT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } \
+             if (hipFuncSetAttribute((const void*)k_s2_scatter<C, S2_SPT_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
   S2_FOR_EACH_C(X)
 #undef X
   // k_s2_count keeps W * P counters: up to 24 windows x S2_P_MAX partitions (SBN_SORT2_LO can push P to the maximum with a narrow window)
   const int cnt_bytes = 24 * S2_P_MAX * 4;
-#define X(C) if (hipFuncSetAttribute((const void*)k_s2_count<C>, hipFuncAttributeMaxDynamicSharedMemorySize, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+#define X(C) if (hipFuncSetAttribute((const void*)k_s2_count<C, S2_SPT>, hipFuncAttributeMaxDynamicSharedMemorySize, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; } \
+             if (hipFuncSetAttribute((const void*)k_s2_count<C, S2_SPT_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, cnt_bytes) != hipSuccess) { (void)hipGetLastError(); ok = false; }
   S2_FOR_EACH_C(X)
 #undef X
   return ok;
@@ -91,7 +93,12 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
   if (g.lo_log > S2_LO_LOG_MAX) return fail(c, SBN_EINVAL, "two-level sort: window of %d bits is too wide", s.c);
   g.P = s.nb >> g.lo_log;
   const int LO = 1 << g.lo_log;
-  g.K = (int)((n + S2_CH - 1) / S2_CH);
+  // scalars per level-1 block: 8192 from 2^22 on (>= 512 blocks of 1024 threads); below that 2048, so that a 2^20 MSM starts 512 blocks instead of 128
+  // (k_s2_count + k_s2_scatter 21 + 95 us -> see DESIGN 4.4 round 4); SBN_SORT2_SPT = 2 / 8 overrides
+  int spt = n <= ((size_t)1 << 21) ? S2_SPT_SMALL : S2_SPT;
+  if (const char* e = getenv("SBN_SORT2_SPT")) { const int v = atoi(e); if (v == S2_SPT || v == S2_SPT_SMALL) spt = v; }
+  const size_t ch = (size_t)1024 * spt;
+  g.K = (int)((n + ch - 1) / ch);
   const size_t WP = (size_t)g.W * g.P;
   const size_t max_sc = ((size_t)g.W * n) / S2_SUB + WP;          // sum over partitions of ceil(cnt / S2_SUB), cnt summing to <= W n
   int rc;
@@ -102,12 +109,13 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
   if ((rc = ensure(c, c->blockhist, max_sc * LO * 4))) return rc;
   uint32_t* cntA = (uint32_t*)c->s2_cnt.p; uint32_t* part_cnt = (uint32_t*)c->s2_part.p; uint32_t* part_off = part_cnt + WP; uint32_t* sc_off = part_off + WP;
   uint32_t* tmp_idx = (uint32_t*)c->s2_idx.p; uint16_t* tmp_lo = (uint16_t*)c->s2_lo.p; uint32_t* bh = (uint32_t*)c->blockhist.p;
-  const size_t lds_a = WP * 4, lds_c = s2_scatter_lds_bytes(g.P);
+  const size_t lds_a = WP * 4, lds_c = s2_scatter_lds_bytes(g.P, spt);
   if (lds_a > (size_t)24 * S2_P_MAX * 4) return fail(c, SBN_EINVAL, "two-level sort: %zu level-1 counters do not fit the LDS granted to k_s2_count", WP);
   {
     ProfScope _ps(c, "k_s2_count");
     switch (s.c) {
-#define X(C) case C: hipLaunchKernelGGL(k_s2_count<C>, dim3(g.K), dim3(1024), lds_a, c->stream, scalars, g, cntA, c->d_bad); break;
+#define X(C) case C: if (spt == S2_SPT) hipLaunchKernelGGL((k_s2_count<C, S2_SPT>), dim3(g.K), dim3(1024), lds_a, c->stream, scalars, g, cntA, c->d_bad); \
+                     else hipLaunchKernelGGL((k_s2_count<C, S2_SPT_SMALL>), dim3(g.K), dim3(1024), lds_a, c->stream, scalars, g, cntA, c->d_bad); break;
       S2_FOR_EACH_C(X)
 #undef X
     }
@@ -117,7 +125,8 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
   {
     ProfScope _ps(c, "k_s2_scatter");
     switch (s.c) {
-#define X(C) case C: hipLaunchKernelGGL(k_s2_scatter<C>, dim3(g.K), dim3(1024), lds_c, c->stream, scalars, g, (const uint32_t*)cntA, (const uint32_t*)part_off, tmp_idx, tmp_lo); break;
+#define X(C) case C: if (spt == S2_SPT) hipLaunchKernelGGL((k_s2_scatter<C, S2_SPT>), dim3(g.K), dim3(1024), lds_c, c->stream, scalars, g, (const uint32_t*)cntA, (const uint32_t*)part_off, tmp_idx, tmp_lo); \
+                     else hipLaunchKernelGGL((k_s2_scatter<C, S2_SPT_SMALL>), dim3(g.K), dim3(1024), lds_c, c->stream, scalars, g, (const uint32_t*)cntA, (const uint32_t*)part_off, tmp_idx, tmp_lo); break;
       S2_FOR_EACH_C(X)
 #undef X
     }

@@ -20,7 +20,8 @@ namespace sbn {
 
 constexpr int S2_LO_LOG_MAX = 11, S2_LO_MAX = 1 << S2_LO_LOG_MAX;      // most buckets per partition (LDS counters of level 2)
 constexpr int S2_P_MAX = 1024;                                        // most partitions per window (one scan lane each in level 1)
-constexpr int S2_SPT = 8, S2_CH = 1024 * S2_SPT;          // scalars per thread / per block in level 1
+constexpr int S2_SPT = 8, S2_CH = 1024 * S2_SPT;          // scalars per thread / per block in level 1 (large inputs)
+constexpr int S2_SPT_SMALL = 2;                           // ... up to 2^21 scalars: 8192 per block would be 128 - 256 blocks, half the chip or less (k_s2_scatter at 2^20: 95 us)
 constexpr int S2_C_MIN = 13, S2_C_MAX = 22;               // window bits this path is built for (P = 2^(c-12) partitions: 2 .. 1024)
 struct S2Geom {
   size_t n;        // scalars
@@ -70,14 +71,14 @@ __device__ __forceinline__ void s2_count_scalar(const s2_u32x8 kk, int P, int lo
   };
   (one(std::integral_constant<int, Ws>{}), ...);
 }
-template <int C>
+template <int C, int SPT>
 __global__ void __launch_bounds__(1024) k_s2_count(const uint32_t* __restrict__ scalars, S2Geom g, uint32_t* __restrict__ cntA, uint32_t* __restrict__ bad) {
-  constexpr int W = S2Shape<C>::W;
+  constexpr int W = S2Shape<C>::W; constexpr int CH = 1024 * SPT;
   const int k = blockIdx.x, P = g.P;
   for (int j = threadIdx.x; j < W * P; j += 1024) s2_lds[j] = 0;
   __syncthreads();
-  for (int i = 0; i < S2_SPT; i++) {
-    const size_t t = (size_t)k * S2_CH + (size_t)i * 1024 + threadIdx.x;
+  for (int i = 0; i < SPT; i++) {
+    const size_t t = (size_t)k * CH + (size_t)i * 1024 + threadIdx.x;
     if (t >= g.n) break;
     const s2_u32x8 kk = s2_load_scalar(scalars + 8 * t);
     if (!s2_is_canonical(kk)) atomicAdd(bad, 1u);       // reported as SBN_EINVAL by the entry point (scalar.rs:87-95)
@@ -138,23 +139,24 @@ __global__ void __launch_bounds__(1024) k_s2_prefix_hi(const uint32_t* __restric
 }
 
 // level 1, pass C: the block's entries of window w, sorted by partition inside LDS and written out as runs.
-// LDS: cnt[P] | base[P] | gdelta[P] | scan tmp[32] | stage_idx[S2_CH] | stage_lo[S2_CH] (u16) | stage_hi[S2_CH] (u16)
-__host__ __device__ inline size_t s2_scatter_lds_bytes(int P) { return ((size_t)3 * P + 32) * 4 + (size_t)S2_CH * 8; }
+// LDS: cnt[P] | base[P] | gdelta[P] | scan tmp[32] | stage_idx[CH] | stage_lo[CH] (u16) | stage_hi[CH] (u16)      (CH = 1024 * SPT)
+__host__ __device__ inline size_t s2_scatter_lds_bytes(int P, int spt = S2_SPT) { return ((size_t)3 * P + 32) * 4 + (size_t)1024 * spt * 8; }
 struct S2ScatterArgs {
   const uint32_t* cntA; const uint32_t* part_off; uint32_t* tmp_idx; uint16_t* tmp_lo;
   size_t n; int P, K, k, lo_log;
 };
-template <int C, int w>
-__device__ __forceinline__ void s2_scatter_window(const s2_u32x8 (&kk)[S2_SPT], uint32_t (&carry)[S2_SPT], const S2ScatterArgs& a) {
+template <int C, int w, int SPT>
+__device__ __forceinline__ void s2_scatter_window(const s2_u32x8 (&kk)[SPT], uint32_t (&carry)[SPT], const S2ScatterArgs& a) {
+  constexpr int CH = 1024 * SPT;
   const int P = a.P, tid = threadIdx.x;
   uint32_t* cnt = s2_lds; uint32_t* base = cnt + P; uint32_t* gdelta = base + P; uint32_t* tmp = gdelta + P;
   uint32_t* stage_idx = tmp + 32;
-  uint16_t* stage_lo = reinterpret_cast<uint16_t*>(stage_idx + S2_CH); uint16_t* stage_hi = stage_lo + S2_CH;
+  uint16_t* stage_lo = reinterpret_cast<uint16_t*>(stage_idx + CH); uint16_t* stage_hi = stage_lo + CH;
   for (int j = tid; j < P; j += 1024) cnt[j] = 0;
   __syncthreads();
-  int d[S2_SPT]; uint32_t rank[S2_SPT];
+  int d[SPT]; uint32_t rank[SPT];
 #pragma unroll
-  for (int i = 0; i < S2_SPT; i++) {
+  for (int i = 0; i < SPT; i++) {
     const int dd = s2_digit<C, w>(kk[i], carry[i]);
     d[i] = dd; rank[i] = 0;
     if (dd != 0) rank[i] = atomicAdd(&cnt[((dd < 0 ? -dd : dd) - 1) >> a.lo_log], 1u);
@@ -167,9 +169,9 @@ __device__ __forceinline__ void s2_scatter_window(const s2_u32x8 (&kk)[S2_SPT], 
     if (tid < P) { base[tid] = r; gdelta[tid] = a.part_off[(size_t)w * P + tid] + a.cntA[((size_t)w * P + tid) * a.K + a.k] - r; }
   }
   __syncthreads();
-  const size_t t0 = (size_t)a.k * S2_CH + tid;
+  const size_t t0 = (size_t)a.k * CH + tid;
 #pragma unroll
-  for (int i = 0; i < S2_SPT; i++) {
+  for (int i = 0; i < SPT; i++) {
     if (d[i] == 0) continue;
     const uint32_t b = (uint32_t)((d[i] < 0 ? -d[i] : d[i]) - 1), hi = b >> a.lo_log;
     const uint32_t pos = base[hi] + rank[i];
@@ -184,22 +186,22 @@ __device__ __forceinline__ void s2_scatter_window(const s2_u32x8 (&kk)[S2_SPT], 
   }
   __syncthreads();
 }
-template <int C, int... Ws>
-__device__ __forceinline__ void s2_scatter_windows(const s2_u32x8 (&kk)[S2_SPT], uint32_t (&carry)[S2_SPT], const S2ScatterArgs& a, std::integer_sequence<int, Ws...>) {
-  (s2_scatter_window<C, Ws>(kk, carry, a), ...);
+template <int C, int SPT, int... Ws>
+__device__ __forceinline__ void s2_scatter_windows(const s2_u32x8 (&kk)[SPT], uint32_t (&carry)[SPT], const S2ScatterArgs& a, std::integer_sequence<int, Ws...>) {
+  (s2_scatter_window<C, Ws, SPT>(kk, carry, a), ...);
 }
-template <int C>
+template <int C, int SPT>
 __global__ void __launch_bounds__(1024) k_s2_scatter(const uint32_t* __restrict__ scalars, S2Geom g, const uint32_t* __restrict__ cntA /* prefixed over k */,
                                                      const uint32_t* __restrict__ part_off, uint32_t* __restrict__ tmp_idx, uint16_t* __restrict__ tmp_lo) {
   S2ScatterArgs a; a.cntA = cntA; a.part_off = part_off; a.tmp_idx = tmp_idx; a.tmp_lo = tmp_lo; a.n = g.n; a.P = g.P; a.K = g.K; a.k = blockIdx.x; a.lo_log = g.lo_log;
-  s2_u32x8 kk[S2_SPT]; uint32_t carry[S2_SPT];
+  s2_u32x8 kk[SPT]; uint32_t carry[SPT];
 #pragma unroll
-  for (int i = 0; i < S2_SPT; i++) {
-    const size_t t = (size_t)blockIdx.x * S2_CH + (size_t)i * 1024 + threadIdx.x;
+  for (int i = 0; i < SPT; i++) {
+    const size_t t = (size_t)blockIdx.x * (1024 * SPT) + (size_t)i * 1024 + threadIdx.x;
     carry[i] = 0;
     kk[i] = t < g.n ? s2_load_scalar(scalars + 8 * t) : (s2_u32x8)(0u);      // zero scalar: every digit 0, no entries
   }
-  s2_scatter_windows<C>(kk, carry, a, std::make_integer_sequence<int, S2Shape<C>::W>{});
+  s2_scatter_windows<C, SPT>(kk, carry, a, std::make_integer_sequence<int, S2Shape<C>::W>{});
 }
 
 // level 2: a block = one sub-chunk (S2_SUB entries of one partition).  Consecutive workgroup ids go round-robin over the 8 XCDs,

@@ -814,6 +814,18 @@ def test_two_level_sort_vs_oracle(ctx_sort2, ol, pr, monkeypatch, c_bits, n):
         assert out == ol.msm_pippenger(sc, pts, 8)
 
 
+@pytest.mark.parametrize("spt", [2, 8])
+def test_two_level_sort_both_block_sizes(ctx_sort2, ol, pr, monkeypatch, spt):
+    """level 1 of the two-level sort with 2048 and with 8192 scalars per block (the automatic choice switches at 2^21 terms): partial last block,
+    exactly one block, several; bit-exact vs the discrete-log identity"""
+    monkeypatch.setenv("SBN_SORT2_SPT", str(spt))
+    for n in (1500, 2048, 8192, 8193, 50000):
+        sc = rand_scalars(n, 7000 + n + spt)
+        pts, dl = tiled_bases(ol, n, min(n, 4096), 11 + n)
+        out, inf = ctx_sort2.msm(sc, pts)
+        assert out == expect_from_dlogs(ol, pr, sc, dl) and not inf, (spt, n)
+
+
 def test_two_level_sort_skew_and_edges(ctx_sort2, ol, pr, sbn, monkeypatch):
     """skewed scalars (one partition of one window holds everything), zero scalars, r - 1, powers of two at the window seams, and
     a non-canonical scalar (rejected, scalar.rs:87-95) on the two-level path"""
