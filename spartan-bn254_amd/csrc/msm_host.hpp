@@ -93,9 +93,10 @@ static int sort2_run(sbn_ctx* c, const uint32_t* scalars, size_t n, const MsmSha
   if (g.lo_log > S2_LO_LOG_MAX) return fail(c, SBN_EINVAL, "two-level sort: window of %d bits is too wide", s.c);
   g.P = s.nb >> g.lo_log;
   const int LO = 1 << g.lo_log;
-  // scalars per level-1 block: 8192 from 2^22 on (>= 512 blocks of 1024 threads); below that 2048, so that a 2^20 MSM starts 512 blocks instead of 128
-  // (k_s2_count + k_s2_scatter 21 + 95 us -> see DESIGN 4.4 round 4); SBN_SORT2_SPT = 2 / 8 overrides
-  int spt = n <= ((size_t)1 << 21) ? S2_SPT_SMALL : S2_SPT;
+  // scalars per level-1 block: 8192, or 2048 while that still leaves runs of >= 32 entries per partition (P <= 64: windows up to 15 bits) and the
+  // input is small enough for 8192 to mean few blocks: a 2^20 MSM (c = 15) starts 512 blocks of 1024 threads instead of 128 (k_s2_count + k_s2_scatter
+  // 26 + 96 -> 18 + 68 us); at 2^21 / 2^22 (c = 17, P = 256: runs of 8) the small blocks lose (sort 0.42 / 0.83 against 0.33 / 0.64 ms).  SBN_SORT2_SPT = 2 / 8 overrides
+  int spt = (n <= ((size_t)1 << 21) && g.P <= 64) ? S2_SPT_SMALL : S2_SPT;
   if (const char* e = getenv("SBN_SORT2_SPT")) { const int v = atoi(e); if (v == S2_SPT || v == S2_SPT_SMALL) spt = v; }
   const size_t ch = (size_t)1024 * spt;
   g.K = (int)((n + ch - 1) / ch);
