@@ -178,7 +178,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if ((rc = ensure(c, c->offs, NB * 4))) return rc;
   if ((rc = ensure(c, c->sorted, J.P * estride * 4))) return rc;
   if ((rc = ensure(c, c->buckets, NB * 128 * (size_t)LPB))) return rc;
-  if ((rc = ensure(c, c->acc_ctr, 64))) return rc;
+  if ((rc = ensure(c, c->acc_ctr, 64 + (ACC_SEG_MAX + 2) * 4))) return rc;      // the counters of the accumulate kernels, then the size bins of the bucket ordering: ONE memset clears both
   if ((rc = ensure(c, c->extra_list, max_extra * sizeof(ExtraItem)))) return rc;
   if ((rc = ensure(c, c->extra_out, max_extra * 128))) return rc;
   if ((rc = ensure(c, c->big_list, max_big * sizeof(BigItem)))) return rc;
@@ -210,7 +210,8 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   uint32_t* sorted = (uint32_t*)c->sorted.p; uint32_t* buckets = (uint32_t*)c->buckets.p;
   AccCounters* ctr = (AccCounters*)c->acc_ctr.p;
 
-  HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(AccCounters), c->stream));
+  static_assert(sizeof(AccCounters) <= 64, "the size bins follow the counters at byte 64");
+  HIPCHK(c, hipMemsetAsync(ctr, 0, 64 + (ACC_SEG_MAX + 2) * 4, c->stream));
   // digits once, then the LDS counting sort
   SortGeom g; memset(&g, 0, sizeof g);
   g.E = estride; g.estride = estride; g.nb = s.nb; g.mode = J.mode; g.ncol = J.da.n; g.tstride = J.da.tstride;
@@ -252,12 +253,11 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   }
   }   // one-level sort
   // bucket order by decreasing load
-  if ((rc = ensure(c, c->size_bins, (ACC_SEG_MAX + 2) * 4))) return rc;
   if ((rc = ensure(c, c->perm, NB * 4))) return rc;
-  HIPCHK(c, hipMemsetAsync(c->size_bins.p, 0, (ACC_SEG_MAX + 2) * 4, c->stream));
-  LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p);
-  LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, (uint32_t*)c->size_bins.p, SEG);
-  LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, (uint32_t*)c->size_bins.p, (uint32_t*)c->perm.p);
+  uint32_t* size_bins = (uint32_t*)((uint8_t*)c->acc_ctr.p + 64);           // cleared with the counters at the start of the job
+  LAUNCH(c, "k_size_sort", k_size_hist, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, size_bins);
+  LAUNCH(c, "k_size_sort", k_size_scan, 1, 64, size_bins, SEG);
+  LAUNCH(c, "k_size_sort", k_size_scatter, (unsigned)((NB + 1023) / 1024), 1024, hist, NB, SEG, size_bins, (uint32_t*)c->perm.p);
   unsigned ab = 256; if (const char* eb = getenv("SBN_ACC_BLOCK")) { int v = atoi(eb); if (v == 64 || v == 128 || v == 256) ab = (unsigned)v; }
   const unsigned agrid = (unsigned)((NB * (size_t)LPB + ab - 1) / ab);
 #define ACC_FIRST_ARGS J.points, NB, s.nb, estride, SEG, hist, offs, sorted, (const uint32_t*)c->perm.p, buckets, ctr, (ExtraItem*)c->extra_list.p, (BigItem*)c->big_list.p
@@ -266,7 +266,6 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   else LAUNCH(c, "k_acc_first", k_acc_first<4>, agrid, ab, ACC_FIRST_ARGS);
 #undef ACC_FIRST_ARGS
   LAUNCH(c, "k_acc_extra", k_acc_extra, 2048, 256, J.points, s.nb, estride, SEG, hist, offs, sorted, ctr, (const ExtraItem*)c->extra_list.p, (uint32_t*)c->extra_out.p);
-  LAUNCH(c, "k_acc_merge", k_acc_merge_few, 1024, 256, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
   LAUNCH(c, "k_acc_merge", k_acc_merge, 4096, 64, ctr, (const BigItem*)c->big_list.p, (const uint32_t*)c->extra_out.p, buckets, LPB);
   // The combine level of a job with few chunks (a single MSM of ~2^20 points, small commits) is a latency chain on a nearly empty chip: the
   // quad-cooperative kernel (256 threads per group of 64 chunks, 3.5 instead of 7.6 us per dependent addition) runs it in 0.115 instead of

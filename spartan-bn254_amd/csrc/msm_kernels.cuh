@@ -467,19 +467,19 @@ __device__ __forceinline__ XYZZ xyzz_mul_small(const XYZZ& v, uint32_t k) {
 // wave), a bucket with many by one whole wave (lane-strided chains, then a wave tree)
 constexpr uint32_t MERGE_LANE_MAX = 12;
 // (`G` = slots per bucket: the extras are folded into the bucket's first slot)
-__global__ void __launch_bounds__(256) k_acc_merge_few(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets, int G) {
+__global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets, int G) {
+  const int lane = threadIdx.x;
   const uint32_t total = ctr->big_count;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  if (total == 0) return;                                  // uniform scalars: no oversized bucket — the launch is a no-op (one launch, not two, since round 4)
+  // buckets with few partials: one lane each
+  for (size_t i = (size_t)blockIdx.x * 64 + lane; i < total; i += (size_t)gridDim.x * 64) {
     const BigItem bi = big[i];
     if (bi.k > MERGE_LANE_MAX) continue;
     XYZZ acc = xyzz_load(buckets + 32 * (size_t)bi.bucket * G);
     for (uint32_t j = 0; j < bi.k; j++) acc = xyzz_add(acc, xyzz_load(extra_out + 32 * (size_t)(bi.base + j)));
     xyzz_store(buckets + 32 * (size_t)bi.bucket * G, acc);
   }
-}
-__global__ void __launch_bounds__(64) k_acc_merge(const AccCounters* __restrict__ ctr, const BigItem* __restrict__ big, const uint32_t* __restrict__ extra_out, uint32_t* __restrict__ buckets, int G) {
-  const int lane = threadIdx.x;
-  const uint32_t total = ctr->big_count;
+  // buckets with many: one wave each (different buckets than above: no ordering between the two loops is needed)
   for (uint32_t i = blockIdx.x; i < total; i += gridDim.x) {
     const BigItem bi = big[i];
     if (bi.k <= MERGE_LANE_MAX) continue;
