@@ -29,9 +29,10 @@ def main():
     out_dir = os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     for sub, suffix in (("trace", ""), ("trace_serial", "_serial")):
-        stats = glob.glob(os.path.join(prof_dir, sub, "**", "*_kernel_stats.csv"), recursive=True)
+        # gpurun merges every run's files into the same local directory: take the NEWEST run's file, never the first the glob returns
+        stats = sorted(glob.glob(os.path.join(prof_dir, sub, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         if stats:
-            rows = list(csv.DictReader(open(stats[0])))
+            rows = list(csv.DictReader(open(stats[-1])))
             with open(os.path.join(out_dir, f"{tag}{suffix}_kernel_stats.csv"), "w", newline="") as f:
                 w = csv.writer(f)
                 w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
@@ -43,7 +44,7 @@ def main():
             print("wrote", f"profiles/{tag}{suffix}_kernel_stats.csv")
     sums = defaultdict(lambda: defaultdict(float)); cnts = defaultdict(lambda: defaultdict(int))
     for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        for path in glob.glob(os.path.join(prof_dir, sub, "**", "*_counter_collection.csv"), recursive=True):
+        for path in sorted(glob.glob(os.path.join(prof_dir, sub, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
             for r in csv.DictReader(open(path)):
                 if r["Counter_Name"] == ctr:
                     k = short(r["Kernel_Name"])
