@@ -41,7 +41,7 @@ struct sbn_ctx {
   std::string err;
   // workspace (grown on demand, never shrunk; no allocation in steady state)
   DevBuf scal_canon, hist, offs, sorted, buckets, red_a, red_b, wsum, stage_scal, stage_pts, out_small;
-  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, sc_tickets, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, size_bins, perm, merged;
+  DevBuf sc_args, sc_partial, sc_out, sc_r, sc_tabs, sc_tickets, gen_tmp, acc_ctr, extra_list, extra_out, big_list, digits, blockhist, perm, merged;
   hipStream_t copy_stream = nullptr;          // H2D of the next row chunk while the current one is being committed
   hipEvent_t z_consumed = nullptr;            // set while a chunked commit is running: recorded when a chunk's scalars have been read
   DevBuf zstage[2], out_rows, comb_partial;
