@@ -25,6 +25,10 @@ static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, siz
   if (env && atoi(env) >= 7 && atoi(env) <= chard) return make_shape(atoi(env));
   if (cmax > chard) cmax = chard;
   if (problems && problems * terms <= 32768) {
+    // one MSM of 512 .. 4096 terms: the narrowest windows, their overloaded buckets (16 - 64 points, the top window's two with n / 2 each) cut into
+    // segments of 8 (run_bucket_job) — 64 buckets per window keep the two reduction levels short: 353 / 371 / 407 us at 2^10 / 2^11 / 2^12 against
+    // 479 / 474 / 478 with the rule below (c = 15, segments of 32); profiles/r04_small_msm_window_sweep.txt
+    if (!shared_bucket_set && problems == 1 && terms >= 512 && terms <= 4096 && cmax >= 8) return make_shape(terms <= 512 ? 8 : 7);
     // expected longest chain ~ mean load + the load of the top window's few buckets (it holds only 254 - (W-1)c bits)
     double bl = 1e300; int bcl = 7;
     for (int c = 7; c <= cmax; c++) {
@@ -167,6 +171,7 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   uint32_t SEG = 32; while (SEG < 2 * mean && SEG < ACC_SEG_MAX) SEG <<= 1;
   // enough segments to fill the chip when a problem has few, heavily loaded buckets (one row, many columns)
   if (NB < 262144) { const size_t total = J.P * estride; uint32_t cap = 32; while ((size_t)cap * 262144 < total && cap < ACC_SEG_MAX) cap <<= 1; if (SEG > cap) SEG = cap; }
+  if (J.mode == MODE_SINGLE && J.da.n >= 512 && J.da.n <= 4096) SEG = 8;       // small single MSMs: short chains, the partials folded by k_acc_merge (choose_shape)
   if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
   // lanes per bucket (k_acc_first<G>): chains of ~32 mixed additions when the buckets are loaded enough to be split
   int LPB = 1; if (J.mode == MODE_SINGLE && mean >= 48) LPB = 2;

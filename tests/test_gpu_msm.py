@@ -819,6 +819,7 @@ def test_two_level_sort_both_block_sizes(ctx_sort2, ol, pr, monkeypatch, spt):
     """level 1 of the two-level sort with 2048 and with 8192 scalars per block (the automatic choice switches at 2^21 terms): partial last block,
     exactly one block, several; bit-exact vs the discrete-log identity"""
     monkeypatch.setenv("SBN_SORT2_SPT", str(spt))
+    monkeypatch.setenv("SBN_MSM_C", "15")            # (small single MSMs would take c = 7 and with it the one-level sort)
     for n in (1500, 2048, 8192, 8193, 50000):
         sc = rand_scalars(n, 7000 + n + spt)
         pts, dl = tiled_bases(ol, n, min(n, 4096), 11 + n)
@@ -849,6 +850,22 @@ def test_two_level_sort_matches_one_level(ctx, ctx_sort2, ol, monkeypatch):
     for c_bits in (15, 16):
         monkeypatch.setenv("SBN_MSM_C", str(c_bits))
         assert ctx.msm(sc, pts) == ctx_sort2.msm(sc, pts)
+
+
+@pytest.mark.parametrize("n", [511, 512, 700, 1024, 4096, 4097])
+def test_small_single_msm_rule(ctx, ol, pr, n):
+    """512 .. 4096 terms take the narrowest windows (c = 8 / 7) with segments of 8 points (choose_shape / run_bucket_job): the sizes on both sides of
+    the rule's edges, with repeated points and edge scalars so that buckets overflow their first segment; vs the oracle's Pippenger"""
+    sc = bytearray(rand_scalars(n, 8100 + n))
+    for i, v in enumerate([0, 1, pr.R - 1, 1 << 253, (1 << 7) - 1, 1 << 6]):
+        sc[32 * i:32 * i + 32] = pr.scalar_to_bytes(v % pr.R)
+    for i in range(40, 40 + n // 4):                         # a quarter of the scalars equal: one bucket per window takes n / 4 entries
+        sc[32 * i:32 * i + 32] = sc[32 * 40:32 * 41]
+    sc = bytes(sc)
+    pts, dl = tiled_bases(ol, n, min(n, 256), 9 + n)
+    out, inf = ctx.msm(sc, pts)
+    assert ctx.prof_last_job()["c"] == (7 if 512 < n <= 4096 else 8 if n == 512 else ctx.prof_last_job()["c"])
+    assert out == ol.msm_pippenger(sc, pts, 8) and not inf
 
 
 @pytest.mark.parametrize("L", [1, 3, 5, 7, 11, 33])
