@@ -174,7 +174,9 @@ static int run_bucket_job(sbn_ctx* c, const BucketJob& J) {
   if (J.mode == MODE_SINGLE && J.da.n >= 512 && J.da.n <= 4096) SEG = 8;       // small single MSMs: short chains, the partials folded by k_acc_merge (choose_shape)
   if (const char* es = getenv("SBN_MSM_SEG")) { int v = atoi(es); if (v >= 8 && v <= (int)ACC_SEG_MAX) SEG = (uint32_t)v; }
   // lanes per bucket (k_acc_first<G>): chains of ~32 mixed additions when the buckets are loaded enough to be split
-  int LPB = 1; if (J.mode == MODE_SINGLE && mean >= 48) LPB = 2;
+  // (only while one lane per bucket would leave the chip short of lanes: at 2^22, c = 17 — 983 k buckets of 64 points — two lanes per bucket accumulate no
+  //  faster (4.74 against 4.77 ms) and make the reduction read two slots per bucket: k_reduce_l1 0.53 against 0.37 ms; tools/sweep_acc_g.sh)
+  int LPB = 1; if (J.mode == MODE_SINGLE && mean >= 48 && NB <= ((size_t)1 << 19)) LPB = 2;
   if (const char* eg = getenv("SBN_ACC_G")) { int v = atoi(eg); if (v == 1 || v == 2 || v == 4) LPB = v; }
   const size_t max_extra = J.P * estride / SEG + 1;
   const size_t max_big = std::min(NB, max_extra);
