@@ -54,7 +54,10 @@ static MsmShape choose_shape(size_t terms, bool shared_bucket_set, int cmax, siz
     MsmShape s = make_shape(c);
     double sets = shared_bucket_set ? 1.0 : (double)s.W;
     // per bucket: ~56 products in the one-level regime (measured at 2^20), ~40 once the reduction runs on millions of buckets
-    double cost = (double)terms * s.W * 10.0 + sets * s.nb * (chard > MSM_C_MAX ? 40.0 : 56.0);
+    // (many rows over one bucket set each are the same throughput regime: the derefs matrix, 4096 rows x 2814 merged columns, c = 11 / 12 / 13 ->
+    //  19.6 / 18.2 / 19.0 ms — with 56 the model ties 11 and 12 and takes 11; tools/sweep_hyrax_bucket.sh)
+    const double per_bucket = (chard > MSM_C_MAX || (shared_bucket_set && problems >= 256)) ? 40.0 : 56.0;
+    double cost = (double)terms * s.W * 10.0 + sets * s.nb * per_bucket;
     // a top window narrower than c - 1 bits fills only 2^tb of its buckets, each 2^(c-1-tb) times over: those go through the
     // segment work list (k_acc_extra / k_acc_merge), measured at about half a window's worth of additions on top
     if (!shared_bucket_set && 254 - (s.W - 1) * c < c - 1) cost += (double)terms * 5.0;
