@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64) k_comb_build(const uint32_t* __restrict__ 
 // register budget of the bucket accumulate kernel, 3 waves per SIMD instead of 2).
 // Rows flagged constant or zero (flags[row] != 0) are left to k_comb_rows_const: their merged form has at most two non-zero
 // scalars, and walking all columns just to find zero digits is a chain of exposed load latencies.
-__global__ void __launch_bounds__(256) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ flags, uint32_t* __restrict__ partial) {
+__global__ void __launch_bounds__(256, 3) k_comb_rows(const uint32_t* __restrict__ table, DigitArgs a, MsmShape s, const uint8_t* __restrict__ flags, uint32_t* __restrict__ partial) {
   const size_t row = blockIdx.x; const unsigned S = gridDim.y;
   if (flags && flags[row] != 0) return;
   XYZZ acc = xyzz_inf();
