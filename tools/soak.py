@@ -49,6 +49,7 @@ while time.time() < t_end:
         assert got == ol.msm_pippenger(k, pts, 8), ("msm", n, sd)
     elif kind == "commit":
         R = rng.choice([1, 5, 64, 100, 1024, 3000]); L = rng.choice([1, 2, 7, 33, 130])
+        if R <= 100 and rng.random() < 0.3: L = rng.choice([256, 300])       # many rows: the window rule of the throughput regime (choose_shape)
         label = rng.choice([b"gens_r1cs_eval", b"gens_r1cs_sat", b"x%d" % sd])
         gx, _ = ol.gens_new(R, label, 8)
         Z = bytearray(special(rand_scalars(L * R, sd), L * R))
